@@ -1,0 +1,511 @@
+// conv.hip -- F5/F10: 3x3 (pad 1) and 1x1 convolution on NCHW fp32 as implicit GEMM on the
+// exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32), plus a direct path for tiny channel counts.
+//
+// Orientation (all three kernels): the MFMA "A" operand is the weight / dY side (rows = output
+// channels), the "B" operand is the activation side (columns = pixels or input channels), so that
+//   forward / dgrad:  D[n][pixel]   -> 32 consecutive pixels per accumulator register: 128-B stores
+//   wgrad:            D[cout][cin]  per tap, reduction over pixels (split-K over pixel chunks,
+//                     partial slabs + deterministic reduce; no atomics)
+// Activations stay NCHW: a pixel tile is 128 (64 for wgrad) consecutive global pixels = whole rows
+// of one image or whole small images, staged into LDS with a zero halo; weights are staged straight
+// from OIHW (no transform pass) into rows of odd stride, which makes every fragment read
+// conflict-free.  fp32 in / fp32 accumulate: bitwise an fma chain, no reduced precision anywhere.
+#include "common.h"
+
+namespace afd {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+static inline int gs_grid(long total, int block = 256) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
+}
+
+// ------------------------------------------------------------------------------------------
+// direct kernels (any shape; used for Cin/Cout < 8 and for planes the tiled path cannot cut)
+// ------------------------------------------------------------------------------------------
+template <int KS>
+__global__ void conv_direct_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                const float* __restrict__ res, float* __restrict__ y,
+                                int Cin, int Cout, int H, int W, int act, long total) {
+  constexpr int T = KS * KS, R = KS / 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xx = i % W, yy = (i / W) % H;
+    const long bc = i / ((long)W * H);
+    const int co = bc % Cout; const long b = bc / Cout;
+    float acc = bias ? bias[co] : 0.f;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* xp = x + (b * Cin + ci) * (long)H * W;
+      const float* wp = w + ((long)co * Cin + ci) * T;
+#pragma unroll
+      for (int a = 0; a < KS; ++a) {
+        const int r = yy + a - R;
+        if (r < 0 || r >= H) continue;
+#pragma unroll
+        for (int c = 0; c < KS; ++c) {
+          const int q = xx + c - R;
+          if (q < 0 || q >= W) continue;
+          acc += wp[a * KS + c] * xp[(long)r * W + q];
+        }
+      }
+    }
+    if (act == 1) acc = gelu_erf(acc);
+    if (res) acc += res[i];
+    y[i] = acc;
+  }
+}
+
+template <int KS>
+__global__ void conv_direct_dgrad(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                  int Cin, int Cout, int H, int W, long total) {
+  constexpr int T = KS * KS, R = KS / 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xx = i % W, yy = (i / W) % H;
+    const long bc = i / ((long)W * H);
+    const int ci = bc % Cin; const long b = bc / Cin;
+    float acc = 0.f;
+    for (int co = 0; co < Cout; ++co) {
+      const float* gp = dy + (b * Cout + co) * (long)H * W;
+      const float* wp = w + ((long)co * Cin + ci) * T;
+#pragma unroll
+      for (int a = 0; a < KS; ++a) {
+        const int r = yy - a + R;
+        if (r < 0 || r >= H) continue;
+#pragma unroll
+        for (int c = 0; c < KS; ++c) {
+          const int q = xx - c + R;
+          if (q < 0 || q >= W) continue;
+          acc += wp[a * KS + c] * gp[(long)r * W + q];
+        }
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+// one workgroup per (co, ci) pair; threads stride over (b, pixel); all taps at once
+template <int KS>
+__global__ __launch_bounds__(256) void conv_direct_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ dw, int B, int Cin, int Cout, int H, int W,
+                                                         int accumulate) {
+  constexpr int T = KS * KS, R = KS / 2;
+  __shared__ float red[16];
+  const int co = blockIdx.x / Cin, ci = blockIdx.x % Cin;
+  float acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = 0.f;
+  const long HW = (long)H * W, P = (long)B * HW;
+  for (long p = threadIdx.x; p < P; p += blockDim.x) {
+    const long b = p / HW; const int pix = p % HW; const int yy = pix / W, xx = pix % W;
+    const float g = dy[(b * Cout + co) * HW + pix];
+    const float* xp = x + (b * Cin + ci) * HW;
+#pragma unroll
+    for (int a = 0; a < KS; ++a) {
+      const int r = yy + a - R;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        const int q = xx + c - R;
+        if (r >= 0 && r < H && q >= 0 && q < W) acc[a * KS + c] += g * xp[(long)r * W + q];
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const float s = block_sum(acc[t], red);
+    if (threadIdx.x == 0) {
+      float* o = dw + ((long)co * Cin + ci) * T + t;
+      *o = accumulate ? *o + s : s;
+    }
+  }
+}
+
+// dbias[n] = sum_{b,pix} dy[b,n,pix]; one workgroup per channel
+__global__ __launch_bounds__(256) void conv_dbias(const float* __restrict__ dy, float* __restrict__ db, int B, int Cout, long HW, int accumulate) {
+  __shared__ float red[16];
+  const int n = blockIdx.x;
+  float s = 0.f;
+  for (long p = threadIdx.x; p < (long)B * HW; p += blockDim.x) {
+    const long b = p / HW, pix = p % HW;
+    s += dy[(b * Cout + n) * HW + pix];
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) db[n] = accumulate ? db[n] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------
+// pixel-tile geometry shared by the MFMA kernels
+// ------------------------------------------------------------------------------------------
+// A tile is PT consecutive global pixels (global pixel = b*HW + y*W + x).  Either it is TR = PT/W
+// whole rows of one image (HW % PT == 0, PT % W == 0) or TI = PT/HW whole images (PT % HW == 0).
+struct TileGeom {
+  int TI, TR;      // images per tile, rows per image in the tile
+  int Wp;          // W + 2*halo
+  int BS;          // LDS floats per (channel, image) block = (TR + 2*halo) * Wp
+  int XS;          // LDS floats per channel
+};
+static inline bool tile_ok(int H, int W, int PT) {
+  const int HW = H * W;
+  return (HW % PT == 0 && PT % W == 0) || (PT % HW == 0);
+}
+static inline TileGeom make_geom(int H, int W, int PT, int halo) {
+  TileGeom g;
+  const int HW = H * W;
+  if (HW >= PT) { g.TI = 1; g.TR = PT / W; } else { g.TI = PT / HW; g.TR = H; }
+  g.Wp = W + 2 * halo;
+  g.BS = (g.TR + 2 * halo) * g.Wp;
+  g.XS = g.TI * g.BS;
+  return g;
+}
+
+// LDS offset (within one channel) of tile pixel m's centre
+__device__ __forceinline__ int pix_lds_off(int m, int W, const TileGeom& g, int halo) {
+  const int per_img = g.TR * W;
+  const int ti = m / per_img, r = (m % per_img) / W, c = m % W;
+  return ti * g.BS + (r + halo) * g.Wp + (c + halo);
+}
+
+// For LDS position `pos` (0 <= pos < g.XS) of a tile starting at global pixel p0: the offset of the
+// source element inside its (b, channel) plane and the image index, or -1 when the position is halo
+// outside the image / beyond the batch.
+__device__ __forceinline__ void pos_source(int pos, long p0, int H, int W, long P, const TileGeom& g, int halo,
+                                           long& img, int& off) {
+  const int HW = H * W;
+  const int ti = pos / g.BS, rem = pos % g.BS;
+  const int rr = rem / g.Wp - halo, cc = rem % g.Wp - halo;
+  const long pimg = p0 / HW + ti;                   // image (batch index) of this block
+  const int row0 = (int)((p0 % HW) / W);            // first tile row inside the image (0 when whole images)
+  const int y = row0 + rr;
+  img = pimg; off = -1;
+  if (cc < 0 || cc >= W || y < 0 || y >= H) return;
+  if (pimg * HW >= P) return;
+  off = y * W + cc;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward / dgrad: D[n][pixel] = sum_{k, tap} Wt[n][k][tap] * X[k][pixel + tap]
+//   FWD:   k = cin,  n = cout, w index ((n*K + k)*T + t)
+//   DGRAD: k = cout, n = cin,  w index ((k*N + n)*T + (T-1-t))   (taps flipped)
+// ------------------------------------------------------------------------------------------
+template <int T, bool DGRAD, int BN, int KC>
+__global__ __launch_bounds__(256) void conv_mfma(const float* __restrict__ x, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, const float* __restrict__ res,
+                                                 float* __restrict__ y, int B, int K, int N, int H, int W, int act,
+                                                 TileGeom g) {
+  constexpr int PT = 128, HALO = (T == 9) ? 1 : 0;
+  constexpr int TM = (BN == 64) ? 2 : 1;            // 32-pixel MFMA tiles per wave
+  constexpr int WS = KC * T + 1;                    // odd row stride of the weight image
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                                  // [BN][WS]
+  float* Xs = smem + BN * WS;                        // [KC][g.XS]
+  const int HW = H * W;
+  const long P = (long)B * HW;
+  const long p0 = (long)blockIdx.y * PT;
+  const int n0 = blockIdx.x * BN;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nw = (BN == 64) ? (wv >> 1) * 32 : 0;                       // wave's first output channel in the tile
+  const int mw = (BN == 64) ? (wv & 1) * 64 : wv * 32;                  // wave's first pixel in the tile
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // chunk-invariant staging plan for X: up to 2 positions per thread
+  int spos[2], soff[2]; long simg[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    spos[e] = threadIdx.x + 256 * e;
+    soff[e] = -1; simg[e] = 0;
+    if (spos[e] < g.XS) pos_source(spos[e], p0, H, W, P, g, HALO, simg[e], soff[e]);
+  }
+  int poff[TM];
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt) poff[mt] = pix_lds_off(mw + mt * 32 + l31, W, g, HALO);
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    __syncthreads();
+    // ---- stage weights
+    if (!DGRAD) {
+      for (int i = threadIdx.x; i < BN * KC * T; i += 256) {
+        const int n = i / (KC * T), r = i % (KC * T);
+        const bool ok = (n0 + n < N) && (k0 + r / T < K);
+        Ws[n * WS + r] = ok ? w[((long)(n0 + n) * K + k0) * T + r] : 0.f;
+      }
+    } else {
+      for (int i = threadIdx.x; i < KC * BN * T; i += 256) {
+        const int kc = i / (BN * T), r = i % (BN * T);
+        const int n = r / T, t = r % T;
+        const bool ok = (n0 + n < N) && (k0 + kc < K);
+        Ws[n * WS + kc * T + t] = ok ? w[((long)(k0 + kc) * N + n0) * T + r] : 0.f;
+      }
+    }
+    // ---- stage activations (zero halo, zero beyond K / batch)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (spos[e] < g.XS) {
+        for (int kc = 0; kc < KC; ++kc) {
+          float v = 0.f;
+          if (soff[e] >= 0 && k0 + kc < K) v = x[(simg[e] * K + k0 + kc) * (long)HW + soff[e]];
+          Xs[kc * g.XS + spos[e]] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- MFMA
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int toff = (T == 9) ? ((t / 3 - 1) * g.Wp + (t % 3 - 1)) : 0;
+      const int tw = DGRAD ? (T - 1 - t) : t;
+#pragma unroll
+      for (int k2 = 0; k2 < KC / 2; ++k2) {
+        const int kc = 2 * k2 + half;
+        const float a = Ws[(nw + l31) * WS + kc * T + tw];
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+          const float bv = Xs[kc * g.XS + poff[mt] + toff];
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- epilogue: row n = (r&3) + 8*(r>>2) + 4*half, column = lane&31
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt) {
+    const long p = p0 + mw + mt * 32 + l31;
+    if (p >= P) continue;
+    const long b = p / HW; const int pix = p % HW;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + nw + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (n >= N) continue;
+      const long idx = (b * N + n) * (long)HW + pix;
+      float v = acc[mt][r];
+      if (bias) v += bias[n];
+      if (act == 1) v = gelu_erf(v);
+      if (res) v += res[idx];
+      y[idx] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: part[split][cout][cin][tap] = sum_{pixels of the split} dY[cout][p] * X[cin][p + tap]
+// ------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ part, int B, int Cin, int Cout, int H, int W,
+                                                       int chunks_per_split, int nchunks, TileGeom g) {
+  constexpr int PT = 64, HALO = (T == 9) ? 1 : 0, S1 = PT + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int XSP = g.XS | 1;                          // odd channel stride
+  float* Gs = smem;                                  // [64][S1]   dY tile (cout rows)
+  float* Xs = smem + 64 * S1;                        // [64][XSP]  X tile (cin rows, haloed)
+  int* Po = reinterpret_cast<int*>(Xs + 64 * XSP);   // [PT] pixel -> LDS offset
+  const int HW = H * W;
+  const long P = (long)B * HW;
+  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, split = blockIdx.z;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nw = (wv >> 1) * 32, cw = (wv & 1) * 32;
+  const int half = lane >> 5, l31 = lane & 31;
+  const bool active = (n0 + nw < Cout) && (c0 + cw < Cin);             // wave-uniform
+
+  if (threadIdx.x < PT) Po[threadIdx.x] = pix_lds_off(threadIdx.x, W, g, HALO);
+
+  // staging plans (chunk-invariant).  dY: thread owns tile pixel pp = tid % 64, rows tid/64 + 4e.
+  const int pp = threadIdx.x & 63;
+  const int gdb = (HW >= PT) ? 0 : pp / HW;                             // image delta inside the tile
+  const int gpix = (HW >= PT) ? pp : pp % HW;                           // pixel inside the image (+ chunk base when HW >= PT)
+  // X: thread owns LDS position xpos = tid % npos of channel group tid / npos
+  const int npos = g.XS;
+  const int ngrp = 256 / npos > 0 ? 256 / npos : 1;
+  const int xgrp = threadIdx.x / npos, xpos = threadIdx.x % npos;
+  const bool xact = (npos <= 256) ? (xgrp < ngrp) : true;
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int cbeg = split * chunks_per_split;
+  const int cend = min(nchunks, cbeg + chunks_per_split);
+  for (int ch = cbeg; ch < cend; ++ch) {
+    const long pc = (long)ch * PT;                   // first global pixel of the chunk
+    __syncthreads();
+    {  // dY tile
+      const long b = pc / HW + gdb;
+      const int pix = (HW >= PT) ? (int)(pc % HW) + gpix : gpix;
+      const bool pin = (pc + pp) < P;
+      for (int e = 0; e < 16; ++e) {
+        const int n = (threadIdx.x >> 6) + 4 * e;
+        float v = 0.f;
+        if (pin && n0 + n < Cout) v = dy[(b * Cout + n0 + n) * (long)HW + pix];
+        Gs[n * S1 + pp] = v;
+      }
+    }
+    if (npos <= 256) {
+      if (xact) {
+        long img; int off;
+        pos_source(xpos, pc, H, W, P, g, HALO, img, off);
+        for (int j = xgrp; j < 64; j += ngrp) {
+          float v = 0.f;
+          if (off >= 0 && c0 + j < Cin) v = x[(img * Cin + c0 + j) * (long)HW + off];
+          Xs[j * XSP + xpos] = v;
+        }
+      }
+    } else {
+      for (int pos = threadIdx.x; pos < npos; pos += 256) {
+        long img; int off;
+        pos_source(pos, pc, H, W, P, g, HALO, img, off);
+        for (int j = 0; j < 64; ++j) {
+          float v = 0.f;
+          if (off >= 0 && c0 + j < Cin) v = x[(img * Cin + c0 + j) * (long)HW + off];
+          Xs[j * XSP + pos] = v;
+        }
+      }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll 4
+      for (int s = 0; s < PT / 2; ++s) {
+        const int pix = 2 * s + half;
+        const float a = Gs[(nw + l31) * S1 + pix];
+        const int xo = (cw + l31) * XSP + Po[pix];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const int toff = (T == 9) ? ((t / 3 - 1) * g.Wp + (t % 3 - 1)) : 0;
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Xs[xo + toff], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!active) return;
+  float* out = part + (long)split * Cout * Cin * T;
+  const int ci = c0 + cw + l31;
+  if (ci < Cin) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + nw + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (n >= Cout) continue;
+#pragma unroll
+      for (int t = 0; t < T; ++t) out[((long)n * Cin + ci) * T + t] = acc[t][r];
+    }
+  }
+}
+
+__global__ void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, long n, int splits, int accumulate) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(long)k * n + i];
+    dw[i] = accumulate ? dw[i] + s : s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host dispatch
+// ------------------------------------------------------------------------------------------
+static inline bool use_mfma(int K, int N, int H, int W, int PT) { return K >= 8 && N >= 8 && tile_ok(H, W, PT); }
+
+template <int T, bool DGRAD>
+static int launch_mfma(const float* x, const float* w, const float* bias, const float* res, float* y,
+                       int B, int K, int N, int H, int W, int act, hipStream_t s) {
+  constexpr int KC = (T == 9) ? 8 : 32;
+  const TileGeom g = make_geom(H, W, 128, T == 9 ? 1 : 0);
+  if (g.XS > 512) return -1;                                            // staging plan holds 2 positions per thread
+  const long P = (long)B * H * W;
+  const unsigned ptiles = (unsigned)((P + 127) / 128);
+  if (N > 32) {
+    const size_t lds = sizeof(float) * (64 * (KC * T + 1) + (size_t)KC * g.XS);
+    hipLaunchKernelGGL((conv_mfma<T, DGRAD, 64, KC>), dim3((N + 63) / 64, ptiles), dim3(256), lds, s, x, w, bias, res, y, B, K, N, H, W, act, g);
+  } else {
+    const size_t lds = sizeof(float) * (32 * (KC * T + 1) + (size_t)KC * g.XS);
+    hipLaunchKernelGGL((conv_mfma<T, DGRAD, 32, KC>), dim3((N + 31) / 32, ptiles), dim3(256), lds, s, x, w, bias, res, y, B, K, N, H, W, act, g);
+  }
+  return 0;
+}
+
+static inline int wgrad_splits(int B, int Cin, int Cout, int H, int W) {
+  const long nchunks = ((long)B * H * W + 63) / 64;
+  const long tiles = (long)((Cout + 63) / 64) * ((Cin + 63) / 64);
+  long s = 1024 / tiles;
+  if (s < 1) s = 1;
+  if (s > nchunks) s = nchunks;
+  return (int)s;
+}
+
+}  // namespace afd
+using namespace afd;
+
+extern "C" {
+
+int afd_conv_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
+                 int B, int Cin, int Cout, int H, int W, int ksize, int act, afd_stream_t st) {
+  AFD_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "afd_conv_fwd: bad argument");
+  AFD_REQUIRE(ksize == 1 || ksize == 3, "afd_conv_fwd: ksize %d not in {1,3}", ksize);
+  AFD_REQUIRE(act == 0 || act == 1, "afd_conv_fwd: act must be 0 or 1");
+  hipStream_t s = as_stream(st);
+  int rc = -1;
+  if (use_mfma(Cin, Cout, H, W, 128))
+    rc = ksize == 3 ? launch_mfma<9, false>(x, w, bias, res, y, B, Cin, Cout, H, W, act, s)
+                    : launch_mfma<1, false>(x, w, bias, res, y, B, Cin, Cout, H, W, act, s);
+  if (rc != 0) {
+    const long total = (long)B * Cout * H * W;
+    if (ksize == 3) hipLaunchKernelGGL(conv_direct_fwd<3>, dim3(gs_grid(total)), dim3(256), 0, s, x, w, bias, res, y, Cin, Cout, H, W, act, total);
+    else hipLaunchKernelGGL(conv_direct_fwd<1>, dim3(gs_grid(total)), dim3(256), 0, s, x, w, bias, res, y, Cin, Cout, H, W, act, total);
+  }
+  return check_launch("afd_conv_fwd");
+}
+
+int afd_conv_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H, int W, int ksize, afd_stream_t st) {
+  AFD_REQUIRE(dy && w && dx && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "afd_conv_dgrad: bad argument");
+  AFD_REQUIRE(ksize == 1 || ksize == 3, "afd_conv_dgrad: ksize %d not in {1,3}", ksize);
+  hipStream_t s = as_stream(st);
+  int rc = -1;
+  if (use_mfma(Cout, Cin, H, W, 128))     // reduction over Cout, output channels = Cin
+    rc = ksize == 3 ? launch_mfma<9, true>(dy, w, nullptr, nullptr, dx, B, Cout, Cin, H, W, 0, s)
+                    : launch_mfma<1, true>(dy, w, nullptr, nullptr, dx, B, Cout, Cin, H, W, 0, s);
+  if (rc != 0) {
+    const long total = (long)B * Cin * H * W;
+    if (ksize == 3) hipLaunchKernelGGL(conv_direct_dgrad<3>, dim3(gs_grid(total)), dim3(256), 0, s, dy, w, dx, Cin, Cout, H, W, total);
+    else hipLaunchKernelGGL(conv_direct_dgrad<1>, dim3(gs_grid(total)), dim3(256), 0, s, dy, w, dx, Cin, Cout, H, W, total);
+  }
+  return check_launch("afd_conv_dgrad");
+}
+
+size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ksize) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  if (!tile_ok(H, W, 64)) return 0;
+  return sizeof(float) * (size_t)wgrad_splits(B, Cin, Cout, H, W) * Cout * Cin * ksize * ksize;
+}
+
+int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
+                   int ksize, int accumulate, void* workspace, afd_stream_t st) {
+  AFD_REQUIRE(x && dy && dw && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "afd_conv_wgrad: bad argument");
+  AFD_REQUIRE(ksize == 1 || ksize == 3, "afd_conv_wgrad: ksize %d not in {1,3}", ksize);
+  hipStream_t s = as_stream(st);
+  const int T = ksize * ksize;
+  const TileGeom g = make_geom(H, W, 64, ksize == 3 ? 1 : 0);
+  if (tile_ok(H, W, 64) && g.XS <= 1024) {
+    AFD_REQUIRE(workspace, "afd_conv_wgrad: workspace is NULL");
+    const int splits = wgrad_splits(B, Cin, Cout, H, W);
+    const int nchunks = (int)(((long)B * H * W + 63) / 64);
+    const int cps = (nchunks + splits - 1) / splits;
+    const size_t lds = sizeof(float) * (64 * 65 + 64 * (size_t)(g.XS | 1)) + sizeof(int) * 64;
+    const dim3 grid((Cout + 63) / 64, (Cin + 63) / 64, splits);
+    float* part = static_cast<float*>(workspace);
+    if (ksize == 3) hipLaunchKernelGGL(conv_wgrad_mfma<9>, grid, dim3(256), lds, s, x, dy, part, B, Cin, Cout, H, W, cps, nchunks, g);
+    else hipLaunchKernelGGL(conv_wgrad_mfma<1>, grid, dim3(256), lds, s, x, dy, part, B, Cin, Cout, H, W, cps, nchunks, g);
+    const long n = (long)Cout * Cin * T;
+    hipLaunchKernelGGL(wgrad_reduce, dim3(gs_grid(n)), dim3(256), 0, s, part, dw, n, splits, accumulate);
+  } else {
+    const dim3 grid((unsigned)(Cout * Cin));
+    if (ksize == 3) hipLaunchKernelGGL(conv_direct_wgrad<3>, grid, dim3(256), 0, s, x, dy, dw, B, Cin, Cout, H, W, accumulate);
+    else hipLaunchKernelGGL(conv_direct_wgrad<1>, grid, dim3(256), 0, s, x, dy, dw, B, Cin, Cout, H, W, accumulate);
+  }
+  if (dbias) hipLaunchKernelGGL(conv_dbias, dim3(Cout), dim3(256), 0, s, dy, dbias, B, Cout, (long)H * W, accumulate);
+  return check_launch("afd_conv_wgrad");
+}
+
+}  // extern "C"

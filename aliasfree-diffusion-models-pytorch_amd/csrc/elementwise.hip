@@ -1,0 +1,270 @@
+// elementwise.hip -- small HBM-bound helpers: GELU, 2x2 max-pool, bilinear 2x (align_corners),
+// batched strided copy (virtual concat), add, column sums, sinusoidal time encoding, SiLU->Linear.
+#include "common.h"
+
+namespace afd {
+
+static inline int gs_grid(long total, int block = 256) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 32768 ? 32768 : g));
+}
+
+#define AFD_GRID_STRIDE(i, total) \
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (total); i += (long)gridDim.x * blockDim.x)
+
+// ---- GELU (nn.GELU exact) -----------------------------------------------------------------
+__global__ void gelu_fwd_k(const float* __restrict__ x, float* __restrict__ y, long n4, long n) {
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  AFD_GRID_STRIDE(i, n4) {
+    float4 v = x4[i];
+    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+    y4[i] = v;
+  }
+  const long tail0 = n4 * 4;
+  AFD_GRID_STRIDE(i, n - tail0) y[tail0 + i] = gelu_erf(x[tail0 + i]);
+}
+__global__ void gelu_bwd_k(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n4, long n) {
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* g4 = reinterpret_cast<const float4*>(dy);
+  float4* o4 = reinterpret_cast<float4*>(dx);
+  AFD_GRID_STRIDE(i, n4) {
+    const float4 v = x4[i], g = g4[i];
+    o4[i] = make_float4(g.x * gelu_erf_grad(v.x), g.y * gelu_erf_grad(v.y), g.z * gelu_erf_grad(v.z), g.w * gelu_erf_grad(v.w));
+  }
+  const long tail0 = n4 * 4;
+  AFD_GRID_STRIDE(i, n - tail0) dx[tail0 + i] = dy[tail0 + i] * gelu_erf_grad(x[tail0 + i]);
+}
+
+// ---- MaxPool2d(2): floor mode, first maximum wins in backward (ATen scan order) ----------
+__global__ void maxpool2_fwd_k(const float* __restrict__ x, float* __restrict__ y, int H, int W, long total) {
+  const int Ho = H / 2, Wo = W / 2;
+  AFD_GRID_STRIDE(i, total) {
+    const int j = i % Wo, r = (i / Wo) % Ho; const long pl = i / ((long)Wo * Ho);
+    const float* p = x + pl * H * W + (long)(2 * r) * W + 2 * j;
+    y[i] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[W], p[W + 1]));
+  }
+}
+__global__ void maxpool2_bwd_k(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int H, int W, long total) {
+  // one thread per INPUT element; odd trailing row/column receive zero
+  const int Ho = H / 2, Wo = W / 2;
+  AFD_GRID_STRIDE(i, total) {
+    const int q = i % W, p = (i / W) % H; const long pl = i / ((long)W * H);
+    const int r = p >> 1, j = q >> 1;
+    float g = 0.f;
+    if (r < Ho && j < Wo) {
+      const float* w = x + pl * H * W + (long)(2 * r) * W + 2 * j;
+      const float v[4] = {w[0], w[1], w[W], w[W + 1]};
+      int arg = 0; float m = v[0];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) if (v[k] > m || (v[k] != v[k] && m == m)) { m = v[k]; arg = k; }
+      if (arg == (p & 1) * 2 + (q & 1)) g = dy[pl * Ho * Wo + (long)r * Wo + j];
+    }
+    dx[i] = g;
+  }
+}
+
+// ---- Upsample(scale_factor=2, bilinear, align_corners=True) -------------------------------
+// src = dst * (H-1)/(2H-1) (ATen area_pixel_compute_scale with align_corners); fp32 like ATen.
+__device__ __forceinline__ void bil_src(int d, int n_in, float scale, int& i0, int& i1, float& l1) {
+  const float s = scale * d;
+  i0 = (int)s; if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = s - i0;
+}
+__global__ void bilinear_up2_fwd_k(const float* __restrict__ x, float* __restrict__ y, int C, int H, int W, long ybs, long total) {
+  const int H2 = 2 * H, W2 = 2 * W;
+  const float sh = H2 > 1 ? (float)(H - 1) / (H2 - 1) : 0.f, sw = W2 > 1 ? (float)(W - 1) / (W2 - 1) : 0.f;
+  AFD_GRID_STRIDE(i, total) {
+    const int q = i % W2, p = (i / W2) % H2; const long bc = i / ((long)W2 * H2);
+    const int c = bc % C; const long b = bc / C;
+    int y0, y1, x0, x1; float ly, lx;
+    bil_src(p, H, sh, y0, y1, ly); bil_src(q, W, sw, x0, x1, lx);
+    const float* s = x + bc * H * W;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    y[b * ybs + (long)c * H2 * W2 + (long)p * W2 + q] =
+        hy * (hx * s[y0 * W + x0] + lx * s[y0 * W + x1]) + ly * (hx * s[y1 * W + x0] + lx * s[y1 * W + x1]);
+  }
+}
+// gather form of the adjoint: each input pixel sums the <= 3x3 output pixels that reference it
+__global__ void bilinear_up2_bwd_k(const float* __restrict__ dy, float* __restrict__ dx, int C, int H, int W, long dybs, long total) {
+  const int H2 = 2 * H, W2 = 2 * W;
+  const float sh = H2 > 1 ? (float)(H - 1) / (H2 - 1) : 0.f, sw = W2 > 1 ? (float)(W - 1) / (W2 - 1) : 0.f;
+  AFD_GRID_STRIDE(i, total) {
+    const int j = i % W, r = (i / W) % H; const long bc = i / ((long)W * H);
+    const int c = bc % C; const long b = bc / C;
+    const float* g = dy + b * dybs + (long)c * H2 * W2;
+    // candidate output rows: those whose y0 or y1 can equal r  -> p in [2r-2, 2r+3]
+    float acc = 0.f;
+    for (int p = max(0, 2 * r - 2); p <= min(H2 - 1, 2 * r + 3); ++p) {
+      int y0, y1; float ly; bil_src(p, H, sh, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == r) wy += 1.f - ly;
+      if (y1 == r) wy += ly;
+      if (wy == 0.f) continue;
+      for (int q = max(0, 2 * j - 2); q <= min(W2 - 1, 2 * j + 3); ++q) {
+        int x0, x1; float lx; bil_src(q, W, sw, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == j) wx += 1.f - lx;
+        if (x1 == j) wx += lx;
+        if (wx != 0.f) acc += wy * wx * g[(long)p * W2 + q];
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+// ---- batched strided copy, add, column sums -----------------------------------------------
+__global__ void copy_batched_k(const float* __restrict__ s, float* __restrict__ d, long n, long sbs, long dbs, long total) {
+  AFD_GRID_STRIDE(i, total) { const long b = i / n, k = i % n; d[b * dbs + k] = s[b * sbs + k]; }
+}
+__global__ void add_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n) {
+  AFD_GRID_STRIDE(i, n) y[i] = a[i] + b[i];
+}
+// out[j] = sum_i in[i*cols + j]; one thread per column, fixed order (deterministic)
+__global__ void colsum_k(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  float s = 0.f;
+  for (int i = 0; i < rows; ++i) s += in[(long)i * cols + j];
+  out[j] = accumulate ? out[j] + s : s;
+}
+
+// ---- time embedding ------------------------------------------------------------------------
+__global__ void pos_encoding_k(const int64_t* __restrict__ t, const float* __restrict__ inv_freq, float* __restrict__ temb, int B, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i % half;
+  const float a = (float)t[b] * inv_freq[k];       // t.float() * inv_freq, one fp32 product (ddpm_models.py:266)
+  temb[(long)b * 2 * half + k] = sinf(a);
+  temb[(long)b * 2 * half + half + k] = cosf(a);
+}
+
+__device__ __forceinline__ float silu(float v) { return v / (1.f + __expf(-v)); }
+__device__ __forceinline__ float silu_grad(float v) { const float s = 1.f / (1.f + __expf(-v)); return s * (1.f + v * (1.f - s)); }
+
+// one wave per output (b, n): lanes stride over K
+__global__ void silu_linear_fwd_k(const float* __restrict__ temb, const float* __restrict__ w, const float* __restrict__ bias,
+                                  float* __restrict__ out, int B, int K, int N) {
+  const long wv = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wv >= (long)B * N) return;
+  const int b = wv / N, n = wv % N;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += silu(temb[(long)b * K + k]) * w[(long)n * K + k];
+  s = wave_sum(s);
+  if (lane == 0) out[wv] = s + (bias ? bias[n] : 0.f);
+}
+// dw[n,k] = sum_b dout[b,n] silu(temb[b,k]);  one thread per (n,k)
+__global__ void silu_linear_dw_k(const float* __restrict__ temb, const float* __restrict__ dout, float* __restrict__ dw,
+                                 int B, int K, int N, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * K) return;
+  const int n = i / K, k = i % K;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += dout[(long)b * N + n] * silu(temb[(long)b * K + k]);
+  dw[i] = accumulate ? dw[i] + s : s;
+}
+__global__ void silu_linear_db_k(const float* __restrict__ dout, float* __restrict__ db, int B, int N, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += dout[(long)b * N + n];
+  db[n] = accumulate ? db[n] + s : s;
+}
+// dtemb[b,k] += silu'(temb[b,k]) * sum_n dout[b,n] w[n,k]
+__global__ void silu_linear_dx_k(const float* __restrict__ temb, const float* __restrict__ w, const float* __restrict__ dout,
+                                 float* __restrict__ dtemb, int B, int K, int N) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * K) return;
+  const int b = i / K, k = i % K;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += dout[(long)b * N + n] * w[(long)n * K + k];
+  dtemb[i] += s * silu_grad(temb[i]);
+}
+
+}  // namespace afd
+using namespace afd;
+
+extern "C" {
+
+int afd_gelu_fwd(const float* x, float* y, long n, afd_stream_t st) {
+  AFD_REQUIRE(x && y && n > 0, "afd_gelu_fwd: bad argument");
+  const bool al = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+  const long n4 = al ? n / 4 : 0;
+  hipLaunchKernelGGL(gelu_fwd_k, dim3(gs_grid(n4 ? n4 : n)), dim3(256), 0, as_stream(st), x, y, n4, n);
+  return check_launch("afd_gelu_fwd");
+}
+int afd_gelu_bwd(const float* x, const float* dy, float* dx, long n, afd_stream_t st) {
+  AFD_REQUIRE(x && dy && dx && n > 0, "afd_gelu_bwd: bad argument");
+  const bool al = (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+  const long n4 = al ? n / 4 : 0;
+  hipLaunchKernelGGL(gelu_bwd_k, dim3(gs_grid(n4 ? n4 : n)), dim3(256), 0, as_stream(st), x, dy, dx, n4, n);
+  return check_launch("afd_gelu_bwd");
+}
+int afd_maxpool2_fwd(const float* x, float* y, int B, int C, int H, int W, afd_stream_t st) {
+  AFD_REQUIRE(x && y && B > 0 && C > 0 && H >= 2 && W >= 2, "afd_maxpool2_fwd: bad argument");
+  const long total = (long)B * C * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(maxpool2_fwd_k, dim3(gs_grid(total)), dim3(256), 0, as_stream(st), x, y, H, W, total);
+  return check_launch("afd_maxpool2_fwd");
+}
+int afd_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int C, int H, int W, afd_stream_t st) {
+  AFD_REQUIRE(x && dy && dx && B > 0 && C > 0 && H >= 2 && W >= 2, "afd_maxpool2_bwd: bad argument");
+  const long total = (long)B * C * H * W;
+  hipLaunchKernelGGL(maxpool2_bwd_k, dim3(gs_grid(total)), dim3(256), 0, as_stream(st), x, dy, dx, H, W, total);
+  return check_launch("afd_maxpool2_bwd");
+}
+int afd_bilinear_up2_fwd(const float* x, float* y, int B, int C, int H, int W, long ybs, afd_stream_t st) {
+  AFD_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "afd_bilinear_up2_fwd: bad argument");
+  if (!ybs) ybs = (long)C * 4 * H * W;
+  const long total = (long)B * C * 4 * H * W;
+  hipLaunchKernelGGL(bilinear_up2_fwd_k, dim3(gs_grid(total)), dim3(256), 0, as_stream(st), x, y, C, H, W, ybs, total);
+  return check_launch("afd_bilinear_up2_fwd");
+}
+int afd_bilinear_up2_bwd(const float* dy, float* dx, int B, int C, int H, int W, long dybs, afd_stream_t st) {
+  AFD_REQUIRE(dy && dx && B > 0 && C > 0 && H > 0 && W > 0, "afd_bilinear_up2_bwd: bad argument");
+  if (!dybs) dybs = (long)C * 4 * H * W;
+  const long total = (long)B * C * H * W;
+  hipLaunchKernelGGL(bilinear_up2_bwd_k, dim3(gs_grid(total)), dim3(256), 0, as_stream(st), dy, dx, C, H, W, dybs, total);
+  return check_launch("afd_bilinear_up2_bwd");
+}
+int afd_copy_batched(const float* src, float* dst, int B, long n, long sbs, long dbs, afd_stream_t st) {
+  AFD_REQUIRE(src && dst && B > 0 && n > 0, "afd_copy_batched: bad argument");
+  if (!sbs) sbs = n;
+  if (!dbs) dbs = n;
+  const long total = (long)B * n;
+  hipLaunchKernelGGL(copy_batched_k, dim3(gs_grid(total)), dim3(256), 0, as_stream(st), src, dst, n, sbs, dbs, total);
+  return check_launch("afd_copy_batched");
+}
+int afd_add(const float* a, const float* b, float* y, long n, afd_stream_t st) {
+  AFD_REQUIRE(a && b && y && n > 0, "afd_add: bad argument");
+  hipLaunchKernelGGL(add_k, dim3(gs_grid(n)), dim3(256), 0, as_stream(st), a, b, y, n);
+  return check_launch("afd_add");
+}
+int afd_colsum(const float* in, float* out, int rows, int cols, int accumulate, afd_stream_t st) {
+  AFD_REQUIRE(in && out && rows > 0 && cols > 0, "afd_colsum: bad argument");
+  hipLaunchKernelGGL(colsum_k, dim3((cols + 255) / 256), dim3(256), 0, as_stream(st), in, out, rows, cols, accumulate);
+  return check_launch("afd_colsum");
+}
+int afd_pos_encoding(const int64_t* t, const float* inv_freq, float* temb, int B, int half, afd_stream_t st) {
+  AFD_REQUIRE(t && inv_freq && temb && B > 0 && half > 0, "afd_pos_encoding: bad argument");
+  hipLaunchKernelGGL(pos_encoding_k, dim3((B * half + 255) / 256), dim3(256), 0, as_stream(st), t, inv_freq, temb, B, half);
+  return check_launch("afd_pos_encoding");
+}
+int afd_silu_linear_fwd(const float* temb, const float* w, const float* bias, float* out, int B, int K, int N, afd_stream_t st) {
+  AFD_REQUIRE(temb && w && out && B > 0 && K > 0 && N > 0, "afd_silu_linear_fwd: bad argument");
+  const long waves = (long)B * N;
+  hipLaunchKernelGGL(silu_linear_fwd_k, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(st), temb, w, bias, out, B, K, N);
+  return check_launch("afd_silu_linear_fwd");
+}
+int afd_silu_linear_bwd(const float* temb, const float* w, const float* dout, float* dw, float* dbias, float* dtemb,
+                        int B, int K, int N, int accumulate, afd_stream_t st) {
+  AFD_REQUIRE(temb && w && dout && dw && B > 0 && K > 0 && N > 0, "afd_silu_linear_bwd: bad argument");
+  hipStream_t s = as_stream(st);
+  hipLaunchKernelGGL(silu_linear_dw_k, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, s, temb, dout, dw, B, K, N, accumulate);
+  if (dbias) hipLaunchKernelGGL(silu_linear_db_k, dim3((N + 255) / 256), dim3(256), 0, s, dout, dbias, B, N, accumulate);
+  if (dtemb) hipLaunchKernelGGL(silu_linear_dx_k, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, s, temb, w, dout, dtemb, B, K, N);
+  return check_launch("afd_silu_linear_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,469 @@
+// filt.hip -- F2/F3/F4: jinc*Kaiser filtered 2x resampling and the filtered GELU, gfx950.
+//
+// Two paths per op:
+//   * fast path (N == 3, square power-of-two planes S in {4..64}): one lane owns one column of one
+//     plane and marches down the rows; the whole column lives in registers, left/right neighbours
+//     come from wave shuffles, so every input element is read from HBM exactly once and every
+//     output written once (8 B/element forward, 12 B/element backward for the fused op).  A wave
+//     carries 64/S planes side by side.  No LDS, no 2x-resolution intermediate in memory.
+//   * general path (any N <= 15, any H, W): one thread per output element, direct tap loops;
+//     the fused op composes up2 -> GELU -> down2 through a caller-provided workspace.
+//
+// Definitions restated from the reference (cross-correlation, zero 'same' padding with
+// lo = (N-1)/2 on the low side, samples on even positions, no x4 gain): filtrs.py:71-94.
+#include "common.h"
+
+namespace afd {
+
+// ------------------------------------------------------------------------------------------
+// general path
+// ------------------------------------------------------------------------------------------
+__global__ void up2_fwd_gen(const float* __restrict__ x, float* __restrict__ y, int C, int H, int W,
+                            long xbs, long ybs, long total, Taps t, int N) {
+  const int lo = (N - 1) / 2, H2 = 2 * H, W2 = 2 * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = i % W2, p = (i / W2) % H2;
+    const long bc = i / ((long)W2 * H2);
+    const int c = bc % C; const long b = bc / C;
+    const float* xp = x + b * xbs + (long)c * H * W;
+    float acc = 0.f;
+    for (int a = 0; a < N; ++a) {
+      const int zr = p + a - lo;
+      if (zr < 0 || zr >= H2 || (zr & 1)) continue;
+      for (int bb = 0; bb < N; ++bb) {
+        const int zc = q + bb - lo;
+        if (zc < 0 || zc >= W2 || (zc & 1)) continue;
+        acc += t.k[a * N + bb] * xp[(zr >> 1) * W + (zc >> 1)];
+      }
+    }
+    y[b * ybs + (long)c * H2 * W2 + (long)p * W2 + q] = acc;
+  }
+}
+
+// adjoint of up2: dx[i,j] = sum_{a,b} k[a,b] * dU[2i - a + lo, 2j - b + lo]
+__global__ void up2_bwd_gen(const float* __restrict__ dy, float* __restrict__ dx, int C, int H, int W,
+                            long dybs, long dxbs, long total, Taps t, int N) {
+  const int lo = (N - 1) / 2, H2 = 2 * H, W2 = 2 * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = i % W, r = (i / W) % H;
+    const long bc = i / ((long)W * H);
+    const int c = bc % C; const long b = bc / C;
+    const float* dp = dy + b * dybs + (long)c * H2 * W2;
+    float acc = 0.f;
+    for (int a = 0; a < N; ++a) {
+      const int p = 2 * r - a + lo;
+      if (p < 0 || p >= H2) continue;
+      for (int bb = 0; bb < N; ++bb) {
+        const int q = 2 * j - bb + lo;
+        if (q < 0 || q >= W2) continue;
+        acc += t.k[a * N + bb] * dp[(long)p * W2 + q];
+      }
+    }
+    dx[b * dxbs + (long)c * H * W + (long)r * W + j] = acc;
+  }
+}
+
+__global__ void down2_fwd_gen(const float* __restrict__ x, float* __restrict__ y, int C, int H, int W,
+                              long xbs, long ybs, long total, Taps t, int N) {
+  const int lo = (N - 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = i % Wo, r = (i / Wo) % Ho;
+    const long bc = i / ((long)Wo * Ho);
+    const int c = bc % C; const long b = bc / C;
+    const float* xp = x + b * xbs + (long)c * H * W;
+    float acc = 0.f;
+    for (int a = 0; a < N; ++a) {
+      const int p = 2 * r + a - lo;
+      if (p < 0 || p >= H) continue;
+      for (int bb = 0; bb < N; ++bb) {
+        const int q = 2 * j + bb - lo;
+        if (q < 0 || q >= W) continue;
+        acc += t.k[a * N + bb] * xp[(long)p * W + q];
+      }
+    }
+    y[b * ybs + (long)c * Ho * Wo + (long)r * Wo + j] = acc;
+  }
+}
+
+// adjoint of down2: dX[p,q] = sum_{a,b : (p-a+lo) even, (q-b+lo) even} k[a,b] dD[(p-a+lo)/2, (q-b+lo)/2]
+__global__ void down2_bwd_gen(const float* __restrict__ dy, float* __restrict__ dx, int C, int H, int W,
+                              long dybs, long dxbs, long total, Taps t, int N) {
+  const int lo = (N - 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = i % W, p = (i / W) % H;
+    const long bc = i / ((long)W * H);
+    const int c = bc % C; const long b = bc / C;
+    const float* dp = dy + b * dybs + (long)c * Ho * Wo;
+    float acc = 0.f;
+    for (int a = 0; a < N; ++a) {
+      const int rr = p - a + lo;
+      if (rr < 0 || (rr & 1) || (rr >> 1) >= Ho) continue;
+      for (int bb = 0; bb < N; ++bb) {
+        const int cc = q - bb + lo;
+        if (cc < 0 || (cc & 1) || (cc >> 1) >= Wo) continue;
+        acc += t.k[a * N + bb] * dp[(long)(rr >> 1) * Wo + (cc >> 1)];
+      }
+    }
+    dx[b * dxbs + (long)c * H * W + (long)p * W + q] = acc;
+  }
+}
+
+// v = GroupNorm-apply(x) + res  (the optional prologue of F4), one element
+__device__ __forceinline__ float prologue(const float* x, long idx, float sc, float sh, const float* res) {
+  float v = x[idx] * sc + sh;
+  if (res) v += res[idx];
+  return v;
+}
+
+__device__ __forceinline__ void plane_affine(const float* stats, const float* gamma, const float* beta,
+                                             long b, int c, float& sc, float& sh) {
+  sc = 1.f; sh = 0.f;
+  if (stats) {
+    const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+    const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    sc = rstd * g;
+    sh = be - mean * sc;
+  }
+}
+
+// workspace helpers of the general fused path
+__global__ void prologue_gen(const float* __restrict__ x, float* __restrict__ v, int C, long HW, long total,
+                             const float* stats, const float* gamma, const float* beta, const float* res) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long bc = i / HW; const int c = bc % C; const long b = bc / C;
+    float sc, sh; plane_affine(stats, gamma, beta, b, c, sc, sh);
+    v[i] = prologue(x, i, sc, sh, res);
+  }
+}
+__global__ void gelu_inplace_gen(float* u, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    u[i] = gelu_erf(u[i]);
+}
+__global__ void gelu_grad_mul_gen(const float* __restrict__ u, float* __restrict__ dg, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    dg[i] *= gelu_erf_grad(u[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// fast path, N == 3, S x S planes.  lane = (plane slot, column)
+// ------------------------------------------------------------------------------------------
+template <int S>
+struct Lane {
+  static constexpr int PPW = kWave / S;                 // planes per wave
+  int col; long plane; bool live;
+  __device__ Lane(long planes) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    col = lane % S;
+    plane = wave * PPW + lane / S;
+    live = plane < planes;
+  }
+  __device__ float left(float v) const { const float s = lane_left(v); return col == 0 ? 0.f : s; }
+  __device__ float right(float v) const { const float s = lane_right(v); return col == S - 1 ? 0.f : s; }
+};
+
+// F2 fast: each lane writes its 2x2 polyphase block per input row as two float2 stores.
+template <int S>
+__global__ __launch_bounds__(256) void up2_fwd_n3(const float* __restrict__ x, float* __restrict__ y,
+                                                  long planes, int C, long xbs, long ybs, Taps3 t) {
+  Lane<S> L(planes);
+  const long b = L.plane / C; const int c = L.plane % C;
+  const float* xp = x + b * xbs + (long)c * S * S + L.col;
+  float xv[S + 1];
+#pragma unroll
+  for (int i = 0; i < S; ++i) xv[i] = L.live ? xp[i * S] : 0.f;
+  xv[S] = 0.f;
+  float2* yp = reinterpret_cast<float2*>(y + b * ybs + (long)c * 4 * S * S) + L.col;
+  float xr = L.right(xv[0]);
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    const float xe = xv[i], xd = xv[i + 1];
+    const float xdr = L.right(xd);
+    float2 r0, r1;
+    r0.x = t.k[4] * xe;                                             // U[2i,   2j]
+    r0.y = t.k[3] * xe + t.k[5] * xr;                               // U[2i,   2j+1]
+    r1.x = t.k[1] * xe + t.k[7] * xd;                               // U[2i+1, 2j]
+    r1.y = t.k[0] * xe + t.k[2] * xr + t.k[6] * xd + t.k[8] * xdr;  // U[2i+1, 2j+1]
+    if (L.live) { yp[(2 * i) * S] = r0; yp[(2 * i + 1) * S] = r1; }
+    xr = xdr;
+  }
+}
+
+// F3 fast: input plane is 2S x 2S, lane j owns input columns 2j, 2j+1 (float2 loads).
+template <int S>   // S = OUTPUT side
+__global__ __launch_bounds__(256) void down2_fwd_n3(const float* __restrict__ x, float* __restrict__ y,
+                                                    long planes, int C, long xbs, long ybs, Taps3 t) {
+  Lane<S> L(planes);
+  const long b = L.plane / C; const int c = L.plane % C;
+  const float2* xp = reinterpret_cast<const float2*>(x + b * xbs + (long)c * 4 * S * S) + L.col;
+  float* yp = y + b * ybs + (long)c * S * S + L.col;
+  float2 prev = make_float2(0.f, 0.f);     // row 2i-1 (zero above the image)
+  float prev_l = 0.f;
+  float2 rows[2 * S];
+#pragma unroll
+  for (int r = 0; r < 2 * S; ++r) rows[r] = L.live ? xp[r * S] : make_float2(0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    const float2 mid = rows[2 * i], nxt = rows[2 * i + 1];
+    const float mid_l = L.left(mid.y), nxt_l = L.left(nxt.y);
+    const float d = t.k[0] * prev_l + t.k[1] * prev.x + t.k[2] * prev.y
+                  + t.k[3] * mid_l  + t.k[4] * mid.x  + t.k[5] * mid.y
+                  + t.k[6] * nxt_l  + t.k[7] * nxt.x  + t.k[8] * nxt.y;
+    if (L.live) yp[i * S] = d;
+    prev = nxt; prev_l = nxt_l;
+  }
+}
+
+// F4 fast forward: y = down2(gelu(up2(v))), v = prologue(x).
+template <int S>
+__global__ __launch_bounds__(256) void filt_act_fwd_n3(const float* __restrict__ x, float* __restrict__ y,
+                                                       long planes, int C, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ res, Taps3 u, Taps3 d) {
+  Lane<S> L(planes);
+  const long b = L.plane / C; const int c = L.plane % C;
+  const long base = L.plane * (long)S * S + L.col;
+  float sc, sh;
+  if (L.live) plane_affine(stats, gamma, beta, b, c, sc, sh); else { sc = 1.f; sh = 0.f; }
+  float xv[S + 1];
+#pragma unroll
+  for (int i = 0; i < S; ++i) xv[i] = L.live ? prologue(x, base + i * S, sc, sh, res) : 0.f;
+  xv[S] = 0.f;
+  float g10p = 0.f, g11p = 0.f, g11lp = 0.f;       // odd row of the previous input row (G[2i-1, .])
+  float xr = L.right(xv[0]);
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    const float xe = xv[i], xd = xv[i + 1];
+    const float xdr = L.right(xd);
+    const float g00 = gelu_erf(u.k[4] * xe);
+    const float g01 = gelu_erf(u.k[3] * xe + u.k[5] * xr);
+    const float g10 = gelu_erf(u.k[1] * xe + u.k[7] * xd);
+    const float g11 = gelu_erf(u.k[0] * xe + u.k[2] * xr + u.k[6] * xd + u.k[8] * xdr);
+    const float g01l = L.left(g01), g11l = L.left(g11);
+    const float out = d.k[0] * g11lp + d.k[1] * g10p + d.k[2] * g11p
+                    + d.k[3] * g01l  + d.k[4] * g00  + d.k[5] * g01
+                    + d.k[6] * g11l  + d.k[7] * g10  + d.k[8] * g11;
+    if (L.live) y[base + i * S] = out;
+    g10p = g10; g11p = g11; g11lp = g11l; xr = xdr;
+  }
+}
+
+// F4 fast backward: dv from (x, dy); U is recomputed, nothing at 2x resolution touches memory.
+//   dG[2i,2j]     = d11 dD[i,j]
+//   dG[2i,2j+1]   = d12 dD[i,j] + d10 dD[i,j+1]
+//   dG[2i+1,2j]   = d21 dD[i,j] + d01 dD[i+1,j]
+//   dG[2i+1,2j+1] = d22 dD[i,j] + d20 dD[i,j+1] + d02 dD[i+1,j] + d00 dD[i+1,j+1]
+//   dU = dG * gelu'(U);   dv[i,j] = sum_{a,b} u[a,b] dU[2i-a+1, 2j-b+1]
+template <int S>
+__global__ __launch_bounds__(256) void filt_act_bwd_n3(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ dv, long planes, int C,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ res,
+                                                       Taps3 u, Taps3 d) {
+  Lane<S> L(planes);
+  const long b = L.plane / C; const int c = L.plane % C;
+  const long base = L.plane * (long)S * S + L.col;
+  float sc, sh;
+  if (L.live) plane_affine(stats, gamma, beta, b, c, sc, sh); else { sc = 1.f; sh = 0.f; }
+  float xv[S + 1], gv[S + 1];
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    xv[i] = L.live ? prologue(x, base + i * S, sc, sh, res) : 0.f;
+    gv[i] = L.live ? dy[base + i * S] : 0.f;
+  }
+  xv[S] = 0.f; gv[S] = 0.f;
+  float u10p = 0.f, u11p = 0.f, u11lp = 0.f;       // dU on the odd row of the previous input row
+  float xr = L.right(xv[0]), gr = L.right(gv[0]);
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    const float xe = xv[i], xd = xv[i + 1], ge = gv[i], gd = gv[i + 1];
+    const float xdr = L.right(xd), gdr = L.right(gd);
+    const float U00 = u.k[4] * xe;
+    const float U01 = u.k[3] * xe + u.k[5] * xr;
+    const float U10 = u.k[1] * xe + u.k[7] * xd;
+    const float U11 = u.k[0] * xe + u.k[2] * xr + u.k[6] * xd + u.k[8] * xdr;
+    const float dU00 = (d.k[4] * ge) * gelu_erf_grad(U00);
+    const float dU01 = (d.k[5] * ge + d.k[3] * gr) * gelu_erf_grad(U01);
+    const float dU10 = (d.k[7] * ge + d.k[1] * gd) * gelu_erf_grad(U10);
+    const float dU11 = (d.k[8] * ge + d.k[6] * gr + d.k[2] * gd + d.k[0] * gdr) * gelu_erf_grad(U11);
+    const float dU01l = L.left(dU01), dU11l = L.left(dU11);
+    const float out = u.k[0] * dU11 + u.k[1] * dU10 + u.k[2] * dU11l
+                    + u.k[3] * dU01 + u.k[4] * dU00 + u.k[5] * dU01l
+                    + u.k[6] * u11p + u.k[7] * u10p + u.k[8] * u11lp;
+    if (L.live) dv[base + i * S] = out;
+    u10p = dU10; u11p = dU11; u11lp = dU11l; xr = xdr; gr = gdr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------
+static inline int gs_grid(long total, int block = 256) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
+}
+static inline bool fast_side(int H, int W) { return H == W && (H == 4 || H == 8 || H == 16 || H == 32 || H == 64); }
+static inline Taps load_taps(const float* k, int N) { Taps t; for (int i = 0; i < N * N; ++i) t.k[i] = k[i]; return t; }
+static inline Taps3 load_taps3(const float* k, bool rot180 = false) {
+  Taps3 t; for (int i = 0; i < 9; ++i) t.k[i] = k[rot180 ? 8 - i : i]; return t;
+}
+
+
+#define AFD_DISPATCH_S(S_, KERNEL, GRID_ARGS, ...)                                          \
+  switch (S_) {                                                                              \
+    case 4:  hipLaunchKernelGGL(KERNEL<4>,  GRID_ARGS, __VA_ARGS__); break;                  \
+    case 8:  hipLaunchKernelGGL(KERNEL<8>,  GRID_ARGS, __VA_ARGS__); break;                  \
+    case 16: hipLaunchKernelGGL(KERNEL<16>, GRID_ARGS, __VA_ARGS__); break;                  \
+    case 32: hipLaunchKernelGGL(KERNEL<32>, GRID_ARGS, __VA_ARGS__); break;                  \
+    default: hipLaunchKernelGGL(KERNEL<64>, GRID_ARGS, __VA_ARGS__); break;                  \
+  }
+
+static inline dim3 fast_grid(long planes, int S) {
+  const long ppw = 64 / S, waves = (planes + ppw - 1) / ppw;
+  return dim3((unsigned)((waves + 3) / 4));
+}
+
+static int check_common(const char* fn, const void* a, const void* b, int B, int C, int H, int W, const float* taps, int N) {
+  AFD_REQUIRE(a && b && taps, "%s: NULL pointer", fn);
+  AFD_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "%s: non-positive shape B=%d C=%d H=%d W=%d", fn, B, C, H, W);
+  AFD_REQUIRE(N >= 1 && N <= AFD_MAX_TAPS, "%s: N=%d outside [1,%d]", fn, N, AFD_MAX_TAPS);
+  return AFD_OK;
+}
+
+static int up2_like(const char* fn, const float* x, float* y, int B, int C, int H, int W, long xbs, long ybs,
+                    const float* taps, int N, bool rot, hipStream_t s) {
+  // y (2H x 2W) = up2(x; taps)   [rot: taps rotated by 180 deg -- used as the adjoint of down2 for N == 3]
+  if (!xbs) xbs = (long)C * H * W;
+  if (!ybs) ybs = (long)C * 4 * H * W;
+  const long planes = (long)B * C;
+  if (N == 3 && fast_side(H, W)) {
+    const Taps3 t = load_taps3(taps, rot);
+    AFD_DISPATCH_S(H, up2_fwd_n3, fast_grid(planes, H), dim3(256), 0, s, x, y, planes, C, xbs, ybs, t);
+  } else {
+    AFD_REQUIRE(!rot, "%s: internal: rot180 only on the fast path", fn);
+    const long total = planes * 4 * H * W;
+    hipLaunchKernelGGL(up2_fwd_gen, dim3(gs_grid(total)), dim3(256), 0, s, x, y, C, H, W, xbs, ybs, total, load_taps(taps, N), N);
+  }
+  return check_launch(fn);
+}
+
+static int down2_like(const char* fn, const float* x, float* y, int B, int C, int H, int W, long xbs, long ybs,
+                      const float* taps, int N, bool rot, hipStream_t s) {
+  // y (ceil(H/2) x ceil(W/2)) = down2(x (H x W); taps)
+  if (!xbs) xbs = (long)C * H * W;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  if (!ybs) ybs = (long)C * Ho * Wo;
+  const long planes = (long)B * C;
+  if (N == 3 && (H % 2 == 0) && (W % 2 == 0) && fast_side(Ho, Wo)) {
+    const Taps3 t = load_taps3(taps, rot);
+    AFD_DISPATCH_S(Ho, down2_fwd_n3, fast_grid(planes, Ho), dim3(256), 0, s, x, y, planes, C, xbs, ybs, t);
+  } else {
+    AFD_REQUIRE(!rot, "%s: internal: rot180 only on the fast path", fn);
+    const long total = planes * Ho * Wo;
+    hipLaunchKernelGGL(down2_fwd_gen, dim3(gs_grid(total)), dim3(256), 0, s, x, y, C, H, W, xbs, ybs, total, load_taps(taps, N), N);
+  }
+  return check_launch(fn);
+}
+
+}  // namespace afd
+
+using namespace afd;
+
+extern "C" {
+
+int afd_filt_up2_fwd(const float* x, float* y, int B, int C, int H, int W, long xbs, long ybs,
+                     const float* taps, int N, afd_stream_t stream) {
+  if (int e = check_common("afd_filt_up2_fwd", x, y, B, C, H, W, taps, N)) return e;
+  return up2_like("afd_filt_up2_fwd", x, y, B, C, H, W, xbs, ybs, taps, N, false, as_stream(stream));
+}
+
+int afd_filt_up2_bwd(const float* dy, float* dx, int B, int C, int H, int W, long dybs, long dxbs,
+                     const float* taps, int N, afd_stream_t stream) {
+  if (int e = check_common("afd_filt_up2_bwd", dy, dx, B, C, H, W, taps, N)) return e;
+  hipStream_t s = as_stream(stream);
+  if (N == 3 && fast_side(H, W))   // adjoint of up2 == down2 with the taps rotated by 180 degrees
+    return down2_like("afd_filt_up2_bwd", dy, dx, B, C, 2 * H, 2 * W, dybs, dxbs, taps, N, true, s);
+  if (!dybs) dybs = (long)C * 4 * H * W;
+  if (!dxbs) dxbs = (long)C * H * W;
+  const long total = (long)B * C * H * W;
+  hipLaunchKernelGGL(up2_bwd_gen, dim3(gs_grid(total)), dim3(256), 0, s, dy, dx, C, H, W, dybs, dxbs, total, load_taps(taps, N), N);
+  return check_launch("afd_filt_up2_bwd");
+}
+
+int afd_filt_down2_fwd(const float* x, float* y, int B, int C, int H, int W, long xbs, long ybs,
+                       const float* taps, int N, afd_stream_t stream) {
+  if (int e = check_common("afd_filt_down2_fwd", x, y, B, C, H, W, taps, N)) return e;
+  return down2_like("afd_filt_down2_fwd", x, y, B, C, H, W, xbs, ybs, taps, N, false, as_stream(stream));
+}
+
+int afd_filt_down2_bwd(const float* dy, float* dx, int B, int C, int H, int W, long dybs, long dxbs,
+                       const float* taps, int N, afd_stream_t stream) {
+  if (int e = check_common("afd_filt_down2_bwd", dy, dx, B, C, H, W, taps, N)) return e;
+  hipStream_t s = as_stream(stream);
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  if (N == 3 && (H % 2 == 0) && (W % 2 == 0) && fast_side(Ho, Wo))   // adjoint of down2 == up2 with rotated taps
+    return up2_like("afd_filt_down2_bwd", dy, dx, B, C, Ho, Wo, dybs, dxbs, taps, N, true, s);
+  if (!dybs) dybs = (long)C * Ho * Wo;
+  if (!dxbs) dxbs = (long)C * H * W;
+  const long total = (long)B * C * H * W;
+  hipLaunchKernelGGL(down2_bwd_gen, dim3(gs_grid(total)), dim3(256), 0, s, dy, dx, C, H, W, dybs, dxbs, total, load_taps(taps, N), N);
+  return check_launch("afd_filt_down2_bwd");
+}
+
+size_t afd_filt_act_workspace_bytes(int B, int C, int H, int W, int N, int backward) {
+  if (N == 3 && fast_side(H, W)) return 0;
+  const size_t e = (size_t)B * C * H * W;
+  // fwd: v (e) + U (4e);  bwd: v (e) + U (4e) + dG (4e)
+  return sizeof(float) * (backward ? 9 * e : 5 * e);
+}
+
+int afd_filt_act_fwd(const float* x, float* y, int B, int C, int H, int W,
+                     const float* stats, const float* gamma, const float* beta, const float* res,
+                     const float* taps_up, const float* taps_down, int N, void* workspace, afd_stream_t stream) {
+  if (int e = check_common("afd_filt_act_fwd", x, y, B, C, H, W, taps_up, N)) return e;
+  AFD_REQUIRE(taps_down, "afd_filt_act_fwd: taps_down is NULL");
+  hipStream_t s = as_stream(stream);
+  const long planes = (long)B * C;
+  if (N == 3 && fast_side(H, W)) {
+    const Taps3 u = load_taps3(taps_up), d = load_taps3(taps_down);
+    AFD_DISPATCH_S(H, filt_act_fwd_n3, fast_grid(planes, H), dim3(256), 0, s, x, y, planes, C, stats, gamma, beta, res, u, d);
+    return check_launch("afd_filt_act_fwd");
+  }
+  AFD_REQUIRE(workspace, "afd_filt_act_fwd: this shape (N=%d, %dx%d) needs a workspace", N, H, W);
+  const long e = planes * H * W;
+  float* v = static_cast<float*>(workspace);
+  float* U = v + e;
+  hipLaunchKernelGGL(prologue_gen, dim3(gs_grid(e)), dim3(256), 0, s, x, v, C, (long)H * W, e, stats, gamma, beta, res);
+  hipLaunchKernelGGL(up2_fwd_gen, dim3(gs_grid(4 * e)), dim3(256), 0, s, v, U, C, H, W, (long)C * H * W, (long)C * 4 * H * W, 4 * e, load_taps(taps_up, N), N);
+  hipLaunchKernelGGL(gelu_inplace_gen, dim3(gs_grid(4 * e)), dim3(256), 0, s, U, 4 * e);
+  hipLaunchKernelGGL(down2_fwd_gen, dim3(gs_grid(e)), dim3(256), 0, s, U, y, C, 2 * H, 2 * W, (long)C * 4 * H * W, (long)C * H * W, e, load_taps(taps_down, N), N);
+  return check_launch("afd_filt_act_fwd");
+}
+
+int afd_filt_act_bwd(const float* x, const float* dy, float* dv, int B, int C, int H, int W,
+                     const float* stats, const float* gamma, const float* beta, const float* res,
+                     const float* taps_up, const float* taps_down, int N, void* workspace, afd_stream_t stream) {
+  if (int e = check_common("afd_filt_act_bwd", x, dy, B, C, H, W, taps_up, N)) return e;
+  AFD_REQUIRE(dv && taps_down, "afd_filt_act_bwd: NULL pointer");
+  hipStream_t s = as_stream(stream);
+  const long planes = (long)B * C;
+  if (N == 3 && fast_side(H, W)) {
+    const Taps3 u = load_taps3(taps_up), d = load_taps3(taps_down);
+    AFD_DISPATCH_S(H, filt_act_bwd_n3, fast_grid(planes, H), dim3(256), 0, s, x, dy, dv, planes, C, stats, gamma, beta, res, u, d);
+    return check_launch("afd_filt_act_bwd");
+  }
+  AFD_REQUIRE(workspace, "afd_filt_act_bwd: this shape (N=%d, %dx%d) needs a workspace", N, H, W);
+  const long e = planes * H * W;
+  float* v = static_cast<float*>(workspace);
+  float* U = v + e;
+  float* dG = U + 4 * e;
+  const long cs = (long)C * H * W, cs4 = 4 * cs;
+  hipLaunchKernelGGL(prologue_gen, dim3(gs_grid(e)), dim3(256), 0, s, x, v, C, (long)H * W, e, stats, gamma, beta, res);
+  hipLaunchKernelGGL(up2_fwd_gen, dim3(gs_grid(4 * e)), dim3(256), 0, s, v, U, C, H, W, cs, cs4, 4 * e, load_taps(taps_up, N), N);
+  hipLaunchKernelGGL(down2_bwd_gen, dim3(gs_grid(4 * e)), dim3(256), 0, s, dy, dG, C, 2 * H, 2 * W, cs, cs4, 4 * e, load_taps(taps_down, N), N);
+  hipLaunchKernelGGL(gelu_grad_mul_gen, dim3(gs_grid(4 * e)), dim3(256), 0, s, U, dG, 4 * e);
+  hipLaunchKernelGGL(up2_bwd_gen, dim3(gs_grid(e)), dim3(256), 0, s, dG, dv, C, H, W, cs4, cs, e, load_taps(taps_up, N), N);
+  return check_launch("afd_filt_act_bwd");
+}
+
+}  // extern "C"

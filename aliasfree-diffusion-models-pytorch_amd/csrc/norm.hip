@@ -1,0 +1,299 @@
+// norm.hip -- F6 GroupNorm(1,C) (one group = the whole C*H*W sample) and the channel LayerNorm of
+// the attention blocks, both on NCHW fp32.
+//
+// GroupNorm forward: one workgroup per sample, the sample stays in registers (float4 x NCH per
+// thread) between the mean pass, the centred-variance pass and the apply, so HBM sees one read and
+// one write (8 B/element; 4 B/element in stats-only mode, used when the apply is folded into the
+// filtered-GELU kernel's load).  Samples too large for registers take a 3-pass loop (L2 re-reads).
+// GroupNorm backward: (1) per-(b,c)-plane sums  A1 = sum dz, A2 = sum dz*xhat  (one wave per plane;
+// these ARE the dgamma/dbeta partials), (2) elementwise dx from the per-sample contractions of A1/A2.
+#include "common.h"
+
+namespace afd {
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm(1, C) forward
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gn_epilogue(float xh, float g, float be, float r, int act, float e) {
+  float z = xh * g + be + r;
+  if (act == 1) z = gelu_erf(z);
+  return z + e;
+}
+
+template <int NCH>   // float4 chunks per thread; n4 <= NCH * blockDim.x
+__global__ __launch_bounds__(1024) void gn_fwd_reg(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ stats,
+                                                   int C, int HW, float eps, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ res, int act,
+                                                   const float* __restrict__ emb) {
+  __shared__ float red[16];
+  const long b = blockIdx.x;
+  const long n = (long)C * HW;
+  const int n4 = (int)(n >> 2);
+  const float4* x4 = reinterpret_cast<const float4*>(x + b * n);
+  float4 v[NCH];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int q = k * blockDim.x + threadIdx.x;
+    v[k] = q < n4 ? x4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+  const float mean = block_sum(s, red) / (float)n;
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int q = k * blockDim.x + threadIdx.x;
+    if (q < n4) {
+      const float a = v[k].x - mean, bb = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+      s2 += (a * a + bb * bb) + (c * c + d * d);
+    }
+  }
+  const float var = block_sum(s2, red) / (float)n;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (threadIdx.x == 0) { stats[2 * b] = mean; stats[2 * b + 1] = rstd; }
+  if (!y) return;
+  float4* y4 = reinterpret_cast<float4*>(y + b * n);
+  const float4* r4 = res ? reinterpret_cast<const float4*>(res + b * n) : nullptr;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int q = k * blockDim.x + threadIdx.x;
+    if (q < n4) {
+      const int c = (q << 2) / HW;                       // HW % 4 == 0 on this path: a chunk never straddles channels
+      const float g = gamma[c], be = beta[c];
+      const float e = emb ? emb[b * C + c] : 0.f;
+      const float4 r = r4 ? r4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 o;
+      o.x = gn_epilogue((v[k].x - mean) * rstd, g, be, r.x, act, e);
+      o.y = gn_epilogue((v[k].y - mean) * rstd, g, be, r.y, act, e);
+      o.z = gn_epilogue((v[k].z - mean) * rstd, g, be, r.z, act, e);
+      o.w = gn_epilogue((v[k].w - mean) * rstd, g, be, r.w, act, e);
+      y4[q] = o;
+    }
+  }
+}
+
+// any C, HW: three passes over global memory (the sample is L2-resident between passes)
+__global__ __launch_bounds__(1024) void gn_fwd_loop(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ stats,
+                                                    int C, int HW, float eps, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const float* __restrict__ res, int act,
+                                                    const float* __restrict__ emb) {
+  __shared__ float red[16];
+  const long b = blockIdx.x;
+  const long n = (long)C * HW;
+  const float* xp = x + b * n;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) s += xp[i];
+  const float mean = block_sum(s, red) / (float)n;
+  float s2 = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) { const float d = xp[i] - mean; s2 += d * d; }
+  const float var = block_sum(s2, red) / (float)n;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (threadIdx.x == 0) { stats[2 * b] = mean; stats[2 * b + 1] = rstd; }
+  if (!y) return;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const int c = (int)(i / HW);
+    y[b * n + i] = gn_epilogue((xp[i] - mean) * rstd, gamma[c], beta[c], res ? res[b * n + i] : 0.f, act,
+                               emb ? emb[b * C + c] : 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm(1, C) backward
+// ------------------------------------------------------------------------------------------
+// dz = dy * act'(z),  z = xhat*gamma + beta + res   (act' = 1 when act == 0)
+__device__ __forceinline__ float gn_dz(float xh, float dyv, float g, float be, float r, int act) {
+  if (act == 1) return dyv * gelu_erf_grad(xh * g + be + r);
+  return dyv;
+}
+
+// one wave per (b, c) plane: part[b,c] = {sum dz*xhat, sum dz};  demb[b,c] = sum dy;  dres = dz
+__global__ __launch_bounds__(256) void gn_bwd_plane(const float* __restrict__ x, const float* __restrict__ dy,
+                                                    const float* __restrict__ stats, int C, int HW, long planes,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ res, int act,
+                                                    float* __restrict__ dres, float* __restrict__ part, float* __restrict__ demb) {
+  const long pl = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (pl >= planes) return;
+  const long b = pl / C; const int c = pl % C;
+  const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+  const float g = gamma[c], be = beta[c];
+  const long base = pl * HW;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int i = lane; i < HW; i += 64) {
+    const float xh = (x[base + i] - mean) * rstd;
+    const float d = dy[base + i];
+    const float dz = gn_dz(xh, d, g, be, res ? res[base + i] : 0.f, act);
+    if (dres) dres[base + i] = dz;
+    s1 += dz * xh; s2 += dz; s3 += d;
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+  if (lane == 0) {
+    part[2 * pl] = s1; part[2 * pl + 1] = s2;
+    if (demb) demb[pl] = s3;
+  }
+}
+
+// per sample: m1 = (1/n) sum_c gamma_c * A2[b,c] (= mean of gamma*dz), m2 = (1/n) sum_c gamma_c * A1[b,c]
+__global__ __launch_bounds__(256) void gn_bwd_sample(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                     int C, float inv_n, float* __restrict__ m12) {
+  __shared__ float red[16];
+  const long b = blockIdx.x;
+  float a = 0.f, c2 = 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float g = gamma[c];
+    a += g * part[2 * (b * C + c) + 1];
+    c2 += g * part[2 * (b * C + c)];
+  }
+  a = block_sum(a, red);
+  c2 = block_sum(c2, red);
+  if (threadIdx.x == 0) { m12[2 * b] = a * inv_n; m12[2 * b + 1] = c2 * inv_n; }
+}
+
+// dx = rstd * (gamma*dz - m1 - xhat*m2)
+__global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
+                                                    const float* __restrict__ stats, const float* __restrict__ m12,
+                                                    int C, int HW, long total, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const float* __restrict__ res, int act,
+                                                    float* __restrict__ dx) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pl = i / HW; const long b = pl / C; const int c = pl % C;
+    const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+    const float g = gamma[c];
+    const float xh = (x[i] - mean) * rstd;
+    const float dz = gn_dz(xh, dy[i], g, beta[c], res ? res[i] : 0.f, act);
+    dx[i] = rstd * (g * dz - m12[2 * b] - xh * m12[2 * b + 1]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over C for every pixel of an NCHW tensor (tokens = pixels)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_c_fwd(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ stats,
+                                                int C, int HW, long pixels, float eps,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= pixels) return;
+  const long b = p / HW; const int l = p % HW;
+  const float* xp = x + b * (long)C * HW + l;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += xp[(long)c * HW];
+  const float mean = s / (float)C;
+  float s2 = 0.f;
+  for (int c = 0; c < C; ++c) { const float d = xp[(long)c * HW] - mean; s2 += d * d; }
+  const float rstd = 1.0f / sqrtf(s2 / (float)C + eps);
+  stats[2 * p] = mean; stats[2 * p + 1] = rstd;
+  float* yp = y + b * (long)C * HW + l;
+  for (int c = 0; c < C; ++c) yp[(long)c * HW] = (xp[(long)c * HW] - mean) * rstd * gamma[c] + beta[c];
+}
+
+__global__ __launch_bounds__(256) void ln_c_bwd_dx(const float* __restrict__ x, const float* __restrict__ dy,
+                                                   const float* __restrict__ stats, int C, int HW, long pixels,
+                                                   const float* __restrict__ gamma, float* __restrict__ dx) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= pixels) return;
+  const long b = p / HW; const int l = p % HW;
+  const long off = b * (long)C * HW + l;
+  const float mean = stats[2 * p], rstd = stats[2 * p + 1];
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float g = gamma[c] * dy[off + (long)c * HW];
+    s1 += g; s2 += g * ((x[off + (long)c * HW] - mean) * rstd);
+  }
+  const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+  for (int c = 0; c < C; ++c) {
+    const float xh = (x[off + (long)c * HW] - mean) * rstd;
+    dx[off + (long)c * HW] = rstd * (gamma[c] * dy[off + (long)c * HW] - m1 - xh * m2);
+  }
+}
+
+// one wave per (b, c) plane: part[b,c] = {sum_l dy*xhat, sum_l dy}
+__global__ __launch_bounds__(256) void ln_c_bwd_plane(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      const float* __restrict__ stats, int C, int HW, long planes,
+                                                      float* __restrict__ part) {
+  const long pl = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (pl >= planes) return;
+  const long b = pl / C;
+  const long base = pl * HW;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lane; i < HW; i += 64) {
+    const long p = b * HW + i;
+    const float xh = (x[base + i] - stats[2 * p]) * stats[2 * p + 1];
+    const float d = dy[base + i];
+    s1 += d * xh; s2 += d;
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) { part[2 * pl] = s1; part[2 * pl + 1] = s2; }
+}
+
+static inline int gs_grid(long total, int block = 256) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
+}
+
+}  // namespace afd
+using namespace afd;
+
+extern "C" {
+
+int afd_groupnorm1_fwd(const float* x, float* y, float* stats_out, int B, int C, int HW, float eps,
+                       const float* gamma, const float* beta, const float* res, int act, const float* emb,
+                       afd_stream_t st) {
+  AFD_REQUIRE(x && stats_out && B > 0 && C > 0 && HW > 0, "afd_groupnorm1_fwd: bad argument");
+  AFD_REQUIRE(!y || (gamma && beta), "afd_groupnorm1_fwd: gamma/beta required when y is written");
+  AFD_REQUIRE(act == 0 || act == 1, "afd_groupnorm1_fwd: act must be 0 or 1");
+  hipStream_t s = as_stream(st);
+  const long n = (long)C * HW;
+  const bool vec = (HW % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0);
+#define AFD_GN_LAUNCH(NCH, T) hipLaunchKernelGGL(gn_fwd_reg<NCH>, dim3(B), dim3(T), 0, s, x, y, stats_out, C, HW, eps, gamma, beta, res, act, emb)
+  if (vec && n <= 65536) {
+    const long n4 = n / 4;
+    if (n4 <= 256) AFD_GN_LAUNCH(1, 256);
+    else if (n4 <= 512) AFD_GN_LAUNCH(2, 256);
+    else if (n4 <= 1024) AFD_GN_LAUNCH(4, 256);
+    else if (n4 <= 2048) AFD_GN_LAUNCH(8, 256);
+    else if (n4 <= 4096) AFD_GN_LAUNCH(4, 1024);
+    else if (n4 <= 8192) AFD_GN_LAUNCH(8, 1024);
+    else AFD_GN_LAUNCH(16, 1024);
+  } else {
+    hipLaunchKernelGGL(gn_fwd_loop, dim3(B), dim3(1024), 0, s, x, y, stats_out, C, HW, eps, gamma, beta, res, act, emb);
+  }
+#undef AFD_GN_LAUNCH
+  return check_launch("afd_groupnorm1_fwd");
+}
+
+int afd_groupnorm1_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
+                       const float* gamma, const float* beta, const float* res, int act,
+                       float* dx, float* dres, float* part, float* demb, afd_stream_t st) {
+  AFD_REQUIRE(x && dy && stats && gamma && beta && dx && part && B > 0 && C > 0 && HW > 0, "afd_groupnorm1_bwd: bad argument");
+  AFD_REQUIRE(act == 0 || act == 1, "afd_groupnorm1_bwd: act must be 0 or 1");
+  hipStream_t s = as_stream(st);
+  const long planes = (long)B * C, total = planes * HW;
+  hipLaunchKernelGGL(gn_bwd_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, x, dy, stats, C, HW, planes, gamma, beta, res, act, dres, part, demb);
+  // per-sample contractions go behind the partials: `part` is (B*C*2 + B*2) floats (see afd.h)
+  float* m12 = part + 2 * planes;
+  hipLaunchKernelGGL(gn_bwd_sample, dim3(B), dim3(256), 0, s, part, gamma, C, 1.0f / (float)((long)C * HW), m12);
+  hipLaunchKernelGGL(gn_bwd_apply, dim3(gs_grid(total)), dim3(256), 0, s, x, dy, stats, m12, C, HW, total, gamma, beta, res, act, dx);
+  return check_launch("afd_groupnorm1_bwd");
+}
+
+int afd_layernorm_c_fwd(const float* x, float* y, float* stats_out, int B, int C, int HW, float eps,
+                        const float* gamma, const float* beta, afd_stream_t st) {
+  AFD_REQUIRE(x && y && stats_out && gamma && beta && B > 0 && C > 0 && HW > 0, "afd_layernorm_c_fwd: bad argument");
+  const long pixels = (long)B * HW;
+  hipLaunchKernelGGL(ln_c_fwd, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, as_stream(st), x, y, stats_out, C, HW, pixels, eps, gamma, beta);
+  return check_launch("afd_layernorm_c_fwd");
+}
+
+int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
+                        const float* gamma, float* dx, float* part, afd_stream_t st) {
+  AFD_REQUIRE(x && dy && stats && gamma && dx && part && B > 0 && C > 0 && HW > 0, "afd_layernorm_c_bwd: bad argument");
+  hipStream_t s = as_stream(st);
+  const long pixels = (long)B * HW, planes = (long)B * C;
+  hipLaunchKernelGGL(ln_c_bwd_dx, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, s, x, dy, stats, C, HW, pixels, gamma, dx);
+  hipLaunchKernelGGL(ln_c_bwd_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, x, dy, stats, C, HW, planes, part);
+  return check_launch("afd_layernorm_c_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+"""F12-F17: the DDPM process (modules/ddpm_models.py:301-436) over the HIP kernels.
+
+Bit-exactness: the schedule tables are built on the host in the reference's op order (fp32
+linspace, sequential cumprod); `sample_timesteps` draws from torch's CPU generator exactly like
+the reference; noise_images / the denoise update / the uint8 quantisation are bit-exact HIP
+restatements (csrc/ddpm.hip).  The sampling loop stays on the device: no per-step H2D copy of `t`
+(the reference does one per step, :362) and no per-step host sync.
+"""
+import logging
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class Diffusion:
+    def __init__(self, noise_steps=1000, beta_start=1e-4, beta_end=0.02, img_size=256, device="cuda"):
+        self.noise_steps, self.beta_start, self.beta_end = noise_steps, beta_start, beta_end
+        self.img_size, self.device = img_size, device
+        beta = self.prepare_noise_schedule()                    # host fp32
+        alpha = 1.0 - beta
+        alpha_hat = torch.cumprod(alpha, dim=0)                 # sequential fp32 product on the host
+        self.beta, self.alpha, self.alpha_hat = beta.to(device), alpha.to(device), alpha_hat.to(device)
+        self.filter = None
+        self._t_cache = {}
+
+    def prepare_noise_schedule(self):
+        return torch.linspace(self.beta_start, self.beta_end, self.noise_steps)
+
+    # F14 ---------------------------------------------------------------------------------
+    def noise_images(self, x, t, eps=None):
+        """-> (x_t, eps).  `eps` may be injected (parity mode); default = device RNG like the reference."""
+        if eps is None:
+            eps = torch.randn_like(x)
+        return ops.noise_images(x, eps, t.to(x.device), self.alpha_hat), eps
+
+    # F13 ---------------------------------------------------------------------------------
+    def sample_timesteps(self, n):
+        return torch.randint(low=1, high=self.noise_steps, size=(n,))     # CPU global generator, t in [1, T-1]
+
+    # F16 ---------------------------------------------------------------------------------
+    def _t_full(self, n, i, device):
+        """Device tensor full((n,), i): built once per (n) as arange and sliced -- no per-step H2D."""
+        key = (n, str(device))
+        tab = self._t_cache.get(key)
+        if tab is None:
+            tab = torch.arange(self.noise_steps, device=device, dtype=torch.long)[:, None].repeat(1, n).contiguous()
+            self._t_cache = {key: tab}
+        return tab[i]
+
+    def _initial_noise(self, n, c, noise_source):
+        shape = (n, c, self.img_size, self.img_size)
+        if noise_source == "device":
+            return torch.randn(shape, device=self.device)
+        return torch.randn(shape).to(self.device)                          # reference: CPU draw, then copy (:360)
+
+    def _step_noise(self, x, noise_source):
+        if noise_source == "cpu":      # parity mode: replay the reference's CPU-path stream
+            return torch.randn(x.shape).to(x.device)
+        return torch.randn_like(x)
+
+    def _loop(self, model, n, image_channels, theta=None, noise_source="reference", keep_float=False):
+        """Shared body of sample / revert.  noise_source: 'reference' (x_T from the CPU generator,
+        per-step noise from the device generator -- what the reference does on a GPU), 'cpu'
+        (everything from the CPU generator: reproduces the reference's CPU run), 'device'."""
+        theta_step = None if theta is None else theta / self.noise_steps
+        model.eval()
+        snaps = []
+        with torch.no_grad():
+            x = self._initial_noise(n, image_channels, noise_source)
+            for i in reversed(range(1, self.noise_steps)):
+                t = self._t_full(n, i, x.device)
+                eps = model(x, t)
+                noise = self._step_noise(x, noise_source) if i > 1 else None
+                x = ops.denoise_step(x, eps, noise, self.alpha, self.alpha_hat, self.beta, i)
+                if theta_step is not None:
+                    x = self.rotate_2d_matrix(x, theta_step, self.filter)
+                if i % 100 == 0:
+                    snaps.append(x)
+        model.train()        # the reference leaves the model in train mode (:379)
+        snaps.append(x)
+        return x, snaps
+
+    def sample(self, model, n, image_channels, theta=None, noise_source="reference", return_float=False):
+        logging.info(f"Sampling {n} new images....")
+        if theta is not None:
+            logging.info(f"Theta {theta} provided. Rotation will be applied.")
+        x, snaps = self._loop(model, n, image_channels, theta, noise_source)
+        xq = ops.quantize_u8(x)
+        rq = ops.quantize_u8(torch.cat(snaps))
+        if return_float:
+            return xq, rq, x
+        return xq, rq
+
+    def revert(self, model, n, image_channels, noise_source="reference"):
+        logging.info(f"Sampling {n} new images....")
+        _, snaps = self._loop(model, n, image_channels, None, noise_source)
+        return ops.quantize_u8(torch.cat(snaps))
+
+    # under development in the reference (:388-419); kept as a host-driven loop over the HIP step
+    def sample_shift(self, model, n, image_channels, shift=None, noise_source="reference"):
+        logging.info(f"Sampling {n} new images....")
+        if shift == 0:
+            shift = None
+        idx = None
+        if shift is not None:
+            dur = np.abs(shift) / self.noise_steps
+            idx = set(np.round(np.arange(0, self.noise_steps, dur)).astype(int)[1:].tolist())
+        model.eval()
+        with torch.no_grad():
+            x = self._initial_noise(n, image_channels, noise_source)
+            for i in reversed(range(1, self.noise_steps)):
+                eps = model(x, self._t_full(n, i, x.device))
+                noise = self._step_noise(x, noise_source) if i > 1 else None
+                x = ops.denoise_step(x, eps, noise, self.alpha, self.alpha_hat, self.beta, i)
+                if idx is not None and i in idx:
+                    x = self.shift_2d_matrix(x, 1 * np.sign(shift), 0, self.device)
+        model.train()
+        return ops.quantize_u8(x)
+
+    # F17 (Config E): the reference rotates on the CPU with scipy every step; so do we, for now
+    # (SURVEY.md section 8f-3 lists the GPU spline as a later row).
+    @staticmethod
+    def rotate_2d_matrix(matrix, degrees, filter=None):
+        from scipy import ndimage
+        dev = matrix.device
+        r = ndimage.rotate(input=matrix.cpu().numpy(), angle=degrees, axes=(2, 3), reshape=False, mode="grid-wrap")
+        return torch.from_numpy(r).to(dev)
+
+    @staticmethod
+    def shift_2d_matrix(matrix, hshift, vshift, device):
+        from scipy import ndimage
+        r = ndimage.shift(input=matrix.cpu().numpy(), shift=(0, 0, vshift, hshift), mode="grid-wrap")
+        return torch.from_numpy(r).to(device)

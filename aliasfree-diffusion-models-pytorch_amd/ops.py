@@ -1,0 +1,502 @@
+"""torch.autograd.Function shells around the C ABI (include/afd.h).
+
+torch is used for device memory, the current HIP stream and the autograd graph -- every FLOP and
+every byte moved on the device goes through libafd_hip.so.  All tensors are fp32, NCHW,
+contiguous, on a HIP device; anything else raises (there is no CPU / eager fallback).
+"""
+import numpy as np
+import torch
+
+from ._lib import AfdError, lib
+
+GN_EPS = 1e-5
+LN_EPS = 1e-5
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise AfdError("afdm: the HIP engine needs tensors on a HIP device (got a CPU tensor); "
+                           "there is no CPU fallback -- move the model and its inputs to 'cuda'")
+        if t.dtype != torch.float32:
+            raise AfdError(f"afdm: fp32 only (got {t.dtype})")
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class Taps:
+    """Host copy of an N x N filter: the kernels take taps as launch arguments, so there is no
+    per-call H2D copy (the reference does one per call: filtrs.py:73,91)."""
+
+    def __init__(self, k):
+        a = k.detach().cpu().numpy() if isinstance(k, torch.Tensor) else np.asarray(k)
+        self.arr = np.ascontiguousarray(a, dtype=np.float32)
+        assert self.arr.ndim == 2 and self.arr.shape[0] == self.arr.shape[1]
+        self.N = int(self.arr.shape[0])
+        self.ptr = self.arr.ctypes.data
+
+    @staticmethod
+    def of(k):
+        return k if isinstance(k, Taps) else Taps(k)
+
+
+# ---------------------------------------------------------------------------------------------
+# F2 / F3 filtered resampling
+# ---------------------------------------------------------------------------------------------
+class FiltUp2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, taps):
+        _chk(x)
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty(B, C, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+        lib().afd_filt_up2_fwd(_p(x), _p(y), B, C, H, W, 0, 0, taps.ptr, taps.N, _stream())
+        ctx.taps, ctx.shape = taps, (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = _c(dy)
+        dx = torch.empty(B, C, H, W, device=dy.device, dtype=torch.float32)
+        lib().afd_filt_up2_bwd(_p(dy), _p(dx), B, C, H, W, 0, 0, ctx.taps.ptr, ctx.taps.N, _stream())
+        return dx, None
+
+
+class FiltDown2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, taps):
+        _chk(x)
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty(B, C, (H + 1) // 2, (W + 1) // 2, device=x.device, dtype=torch.float32)
+        lib().afd_filt_down2_fwd(_p(x), _p(y), B, C, H, W, 0, 0, taps.ptr, taps.N, _stream())
+        ctx.taps, ctx.shape = taps, (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = _c(dy)
+        dx = torch.empty(B, C, H, W, device=dy.device, dtype=torch.float32)
+        lib().afd_filt_down2_bwd(_p(dy), _p(dx), B, C, H, W, 0, 0, ctx.taps.ptr, ctx.taps.N, _stream())
+        return dx, None
+
+
+def _act_ws(B, C, H, W, N, backward, device):
+    nbytes = lib().afd_filt_act_workspace_bytes(B, C, H, W, N, backward)
+    return torch.empty(nbytes // 4, device=device, dtype=torch.float32) if nbytes else None
+
+
+class FiltAct(torch.autograd.Function):
+    """y = down2(GELU(up2(x)))   (ddpm_utils.py:123-125) with no fused prologue."""
+
+    @staticmethod
+    def forward(ctx, x, tu, td):
+        _chk(x)
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        ws = _act_ws(B, C, H, W, tu.N, 0, x.device)
+        lib().afd_filt_act_fwd(_p(x), _p(y), B, C, H, W, None, None, None, None, tu.ptr, td.ptr, tu.N, _p(ws), _stream())
+        ctx.save_for_backward(x)
+        ctx.tu, ctx.td = tu, td
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        ws = _act_ws(B, C, H, W, ctx.tu.N, 1, x.device)
+        lib().afd_filt_act_bwd(_p(x), _p(dy), _p(dx), B, C, H, W, None, None, None, None,
+                               ctx.tu.ptr, ctx.td.ptr, ctx.tu.N, _p(ws), _stream())
+        return dx, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# F6 GroupNorm(1, C) with fused epilogues / fused filtered GELU
+# ---------------------------------------------------------------------------------------------
+def _gn_param_grads(part, B, C):
+    """(B,C,2) partials -> dgamma (C,), dbeta (C,) via the deterministic column sum."""
+    out = torch.empty(C, 2, device=part.device, dtype=torch.float32)
+    lib().afd_colsum(_p(part), _p(out), B, 2 * C, 0, _stream())
+    return out[:, 0].contiguous(), out[:, 1].contiguous()
+
+
+class GroupNorm1(torch.autograd.Function):
+    """y = act(GroupNorm(1,C)(x)*gamma + beta + res) + emb[b,c]      (one HBM round trip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, emb, act):
+        _chk(x, gamma, beta, res, emb)
+        x, res, emb = _c(x), _c(res), _c(emb)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(B, 2, device=x.device, dtype=torch.float32)
+        lib().afd_groupnorm1_fwd(_p(x), _p(y), _p(stats), B, C, H * W, GN_EPS, _p(gamma), _p(beta), _p(res), act,
+                                 _p(emb), _stream())
+        ctx.save_for_backward(x, gamma, beta, res, stats)
+        ctx.act, ctx.has_emb = act, emb is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, res, stats = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        dres = None
+        if res is not None:
+            dres = dy if ctx.act == 0 else torch.empty_like(x)      # act == 0: d(res) is dy itself
+        part = torch.empty(B * C * 2 + B * 2, device=x.device, dtype=torch.float32)
+        demb = torch.empty(B, C, device=x.device, dtype=torch.float32) if ctx.has_emb else None
+        lib().afd_groupnorm1_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(beta), _p(res), ctx.act,
+                                 _p(dx), _p(dres) if (res is not None and ctx.act == 1) else None, _p(part), _p(demb), _stream())
+        dgamma, dbeta = _gn_param_grads(part, B, C)
+        return dx, dgamma, dbeta, dres, demb, None
+
+
+class GroupNormFiltAct(torch.autograd.Function):
+    """y = down2(GELU(up2(GroupNorm(1,C)(x)*gamma + beta + res)))    (ddpm_utils.py:122-125,127-131).
+
+    Forward: a stats-only pass over x (4 B/elem) then the fused kernel applies the normalisation
+    and the residual inside its load (8 B/elem [+4 with res]); the normalised tensor and the 2x
+    intermediate never exist in memory."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, tu, td):
+        _chk(x, gamma, beta, res)
+        x, res = _c(x), _c(res)
+        B, C, H, W = x.shape
+        stats = torch.empty(B, 2, device=x.device, dtype=torch.float32)
+        L = lib()
+        L.afd_groupnorm1_fwd(_p(x), None, _p(stats), B, C, H * W, GN_EPS, None, None, None, 0, None, _stream())
+        y = torch.empty_like(x)
+        ws = _act_ws(B, C, H, W, tu.N, 0, x.device)
+        L.afd_filt_act_fwd(_p(x), _p(y), B, C, H, W, _p(stats), _p(gamma), _p(beta), _p(res), tu.ptr, td.ptr, tu.N,
+                           _p(ws), _stream())
+        ctx.save_for_backward(x, gamma, beta, res, stats)
+        ctx.tu, ctx.td = tu, td
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, res, stats = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dy = _c(dy)
+        L = lib()
+        dv = torch.empty_like(x)
+        ws = _act_ws(B, C, H, W, ctx.tu.N, 1, x.device)
+        L.afd_filt_act_bwd(_p(x), _p(dy), _p(dv), B, C, H, W, _p(stats), _p(gamma), _p(beta), _p(res),
+                           ctx.tu.ptr, ctx.td.ptr, ctx.tu.N, _p(ws), _stream())
+        dx = torch.empty_like(x)
+        part = torch.empty(B * C * 2 + B * 2, device=x.device, dtype=torch.float32)
+        L.afd_groupnorm1_bwd(_p(x), _p(dv), _p(stats), B, C, H * W, _p(gamma), _p(beta), None, 0,
+                             _p(dx), None, _p(part), None, _stream())
+        dgamma, dbeta = _gn_param_grads(part, B, C)
+        return dx, dgamma, dbeta, (dv if res is not None else None), None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# F5 / F10 convolution (3x3 pad 1, 1x1)
+# ---------------------------------------------------------------------------------------------
+class Conv(torch.autograd.Function):
+    """y = conv(x, w) + bias + res.  (The GELU epilogue is only used by `conv_infer`.)"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, res):
+        _chk(x, w, bias, res)
+        x, w, res = _c(x), _c(w), _c(res)
+        B, Cin, H, W = x.shape
+        Cout, ks = w.shape[0], w.shape[-1]
+        y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
+        lib().afd_conv_fwd(_p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Cout, H, W, ks, 0, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.has_bias, ctx.has_res = bias is not None, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, Cin, H, W = x.shape
+        Cout, ks = w.shape[0], w.shape[-1]
+        dy = _c(dy)
+        L = lib()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.afd_conv_dgrad(_p(dy), _p(w), _p(dx), B, Cin, Cout, H, W, ks, _stream())
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            db = torch.empty(Cout, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            nbytes = L.afd_conv_wgrad_workspace_bytes(B, Cin, Cout, H, W, ks)
+            ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+            L.afd_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), B, Cin, Cout, H, W, ks, 0, _p(ws), _stream())
+        return dx, dw, db, (dy if ctx.has_res else None)
+
+
+def conv(x, w, bias=None, res=None):
+    return Conv.apply(x, w, bias, res)
+
+
+def conv_infer(x, w, bias=None, res=None, act=0):
+    """No-grad convolution with the fused GELU epilogue."""
+    _chk(x, w, bias, res)
+    x, w, res = _c(x), _c(w), _c(res)
+    B, Cin, H, W = x.shape
+    Cout, ks = w.shape[0], w.shape[-1]
+    y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
+    lib().afd_conv_fwd(_p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Cout, H, W, ks, act, _stream())
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# F10 attention block pieces
+# ---------------------------------------------------------------------------------------------
+class LayerNormC(torch.autograd.Function):
+    """nn.LayerNorm([C]) applied to the (B, L, C) token view of an NCHW tensor, without the transposes."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        _chk(x, gamma, beta)
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(B, H * W, 2, device=x.device, dtype=torch.float32)
+        lib().afd_layernorm_c_fwd(_p(x), _p(y), _p(stats), B, C, H * W, LN_EPS, _p(gamma), _p(beta), _stream())
+        ctx.save_for_backward(x, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, stats = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        part = torch.empty(B, C, 2, device=x.device, dtype=torch.float32)
+        lib().afd_layernorm_c_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(dx), _p(part), _stream())
+        dgamma, dbeta = _gn_param_grads(part, B, C)
+        return dx, dgamma, dbeta
+
+
+class Attention(torch.autograd.Function):
+    """softmax(QK^T/sqrt(d))V on qkv (B, 3C, H, W) -> (B, C, H, W); scores never materialised."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        _chk(qkv)
+        qkv = _c(qkv)
+        B, C3, H, W = qkv.shape
+        C, L = C3 // 3, H * W
+        o = torch.empty(B, C, H, W, device=qkv.device, dtype=torch.float32)
+        lse = torch.empty(B, heads, L, device=qkv.device, dtype=torch.float32)
+        lib().afd_attn_fwd(_p(qkv), _p(o), _p(lse), B, heads, C // heads, L, _stream())
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        B, C3, H, W = qkv.shape
+        C, L = C3 // 3, H * W
+        do = _c(do)
+        dqkv = torch.empty_like(qkv)
+        lib().afd_attn_bwd(_p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), B, ctx.heads, C // ctx.heads, L, _stream())
+        return dqkv, None
+
+
+class Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        x = _c(x)
+        y = torch.empty_like(x)
+        lib().afd_gelu_fwd(_p(x), _p(y), x.numel(), _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        lib().afd_gelu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream())
+        return dx
+
+
+# ---------------------------------------------------------------------------------------------
+# resampling of variants 0 / 2, concat
+# ---------------------------------------------------------------------------------------------
+class MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = torch.empty(B, C, H // 2, W // 2, device=x.device, dtype=torch.float32)
+        lib().afd_maxpool2_fwd(_p(x), _p(y), B, C, H, W, _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        lib().afd_maxpool2_bwd(_p(x), _p(dy), _p(dx), B, C, H, W, _stream())
+        return dx
+
+
+class UpCat(torch.autograd.Function):
+    """cat([skip, up2x(x)], dim=1) in one buffer: the upsampler writes straight into the channel
+    slice (ddpm_utils.py:241-242 / :354-355 / :413-414).  mode 'filt' = custom_upsample,
+    'bilinear' = nn.Upsample(2, bilinear, align_corners=True)."""
+
+    @staticmethod
+    def forward(ctx, x, skip, taps, mode):
+        _chk(x, skip)
+        x, skip = _c(x), _c(skip)
+        B, C, H, W = x.shape
+        Cs = skip.shape[1]
+        assert skip.shape[2] == 2 * H and skip.shape[3] == 2 * W
+        plane = 4 * H * W
+        out = torch.empty(B, Cs + C, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+        L = lib()
+        up_ptr = out.data_ptr() + 4 * Cs * plane
+        bs = (Cs + C) * plane
+        if mode == "filt":
+            L.afd_filt_up2_fwd(_p(x), up_ptr, B, C, H, W, 0, bs, taps.ptr, taps.N, _stream())
+        else:
+            L.afd_bilinear_up2_fwd(_p(x), up_ptr, B, C, H, W, bs, _stream())
+        L.afd_copy_batched(_p(skip), _p(out), B, Cs * plane, 0, bs, _stream())
+        ctx.taps, ctx.mode, ctx.dims = taps, mode, (B, C, Cs, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C, Cs, H, W = ctx.dims
+        dout = _c(dout)
+        plane = 4 * H * W
+        bs = (Cs + C) * plane
+        L = lib()
+        dx = torch.empty(B, C, H, W, device=dout.device, dtype=torch.float32)
+        dskip = torch.empty(B, Cs, 2 * H, 2 * W, device=dout.device, dtype=torch.float32)
+        up_ptr = dout.data_ptr() + 4 * Cs * plane
+        if ctx.mode == "filt":
+            L.afd_filt_up2_bwd(up_ptr, _p(dx), B, C, H, W, bs, 0, ctx.taps.ptr, ctx.taps.N, _stream())
+        else:
+            L.afd_bilinear_up2_bwd(up_ptr, _p(dx), B, C, H, W, bs, _stream())
+        L.afd_copy_batched(_p(dout), _p(dskip), B, Cs * plane, bs, 0, _stream())
+        return dx, dskip, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# F9 time embedding
+# ---------------------------------------------------------------------------------------------
+def pos_encoding(t, inv_freq):
+    """(B,) int64 timesteps -> (B, 2*half) fp32 [sin | cos]   (ddpm_models.py:261-269)."""
+    if not t.is_cuda:
+        raise AfdError("afdm: timesteps must live on the HIP device")
+    t = t.contiguous()
+    B, half = t.shape[0], inv_freq.shape[0]
+    out = torch.empty(B, 2 * half, device=t.device, dtype=torch.float32)
+    lib().afd_pos_encoding(_p(t), _p(inv_freq), _p(out), B, half, _stream())
+    return out
+
+
+class SiluLinear(torch.autograd.Function):
+    """emb_layer = nn.Sequential(nn.SiLU(), nn.Linear(emb_dim, C))   (ddpm_utils.py:208-214)."""
+
+    @staticmethod
+    def forward(ctx, temb, w, bias):
+        _chk(temb, w, bias)
+        temb, w = _c(temb), _c(w)
+        B, K = temb.shape
+        N = w.shape[0]
+        out = torch.empty(B, N, device=temb.device, dtype=torch.float32)
+        lib().afd_silu_linear_fwd(_p(temb), _p(w), _p(bias), _p(out), B, K, N, _stream())
+        ctx.save_for_backward(temb, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        temb, w = ctx.saved_tensors
+        B, K = temb.shape
+        N = w.shape[0]
+        dout = _c(dout)
+        dw = torch.empty_like(w)
+        db = torch.empty(N, device=w.device, dtype=torch.float32)
+        dtemb = torch.zeros_like(temb) if ctx.needs_input_grad[0] else None
+        lib().afd_silu_linear_bwd(_p(temb), _p(w), _p(dout), _p(dw), _p(db), _p(dtemb), B, K, N, 0, _stream())
+        return dtemb, dw, db
+
+
+# ---------------------------------------------------------------------------------------------
+# F14 / F15 / F16
+# ---------------------------------------------------------------------------------------------
+def noise_images(x, eps, t, alpha_hat):
+    _chk(x, eps, alpha_hat)
+    x, eps = _c(x), _c(eps)
+    out = torch.empty_like(x)
+    lib().afd_noise_images(_p(x), _p(eps), _p(t.contiguous()), _p(alpha_hat), _p(out), x.shape[0],
+                           x.numel() // x.shape[0], _stream())
+    return out
+
+
+def denoise_step(x, eps_pred, noise, alpha, alpha_hat, beta, i, out=None):
+    _chk(x, eps_pred, noise)
+    x, eps_pred, noise = _c(x), _c(eps_pred), _c(noise)
+    out = torch.empty_like(x) if out is None else out
+    lib().afd_denoise_step(_p(x), _p(eps_pred), _p(noise), _p(alpha), _p(alpha_hat), _p(beta), int(i), _p(out),
+                           x.numel(), _stream())
+    return out
+
+
+def quantize_u8(x):
+    _chk(x)
+    x = _c(x)
+    out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    lib().afd_quantize_u8(_p(x), _p(out), x.numel(), _stream())
+    return out
+
+
+class MseLoss(torch.autograd.Function):
+    """nn.MSELoss() (mean reduction), deterministic two-stage sum  (ddpm_utils.py:490,503)."""
+
+    @staticmethod
+    def forward(ctx, target, pred):
+        _chk(target, pred)
+        target, pred = _c(target), _c(pred)
+        loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+        ws = torch.empty(4096, device=pred.device, dtype=torch.float32)
+        lib().afd_mse_fwd(_p(pred), _p(target), _p(loss), _p(ws), pred.numel(), _stream())
+        ctx.save_for_backward(target, pred)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        target, pred = ctx.saved_tensors
+        dloss = dloss.reshape(1).contiguous()
+        dpred = torch.empty_like(pred)
+        lib().afd_mse_bwd(_p(pred), _p(target), _p(dloss), _p(dpred), pred.numel(), _stream())
+        return None, dpred
+
+
+def mse_loss(target, pred):
+    return MseLoss.apply(target, pred)

@@ -1,0 +1,101 @@
+"""F11: the UNet (modules/ddpm_models.py:40-298) -- same constructor, same `state_dict`, HIP forward.
+
+The reference spells the five variants out as five copies of one layer list; here one table says
+which stage / block kind each variant uses and a single constructor builds it.
+"""
+import torch
+import torch.nn as nn
+
+from . import blocks as K
+from . import ops
+
+# variant -> (block factory for inc/bot*, down factory, up factory, needs f_settings, banner)
+_VARIANTS = {
+    0: ("plain", K.Down, K.Up, False, "Original UNet"),
+    1: ("plain", K.Down_FF, K.Up_FF, True, "Modified UNet: aliasing filters in up and downsampling"),
+    2: ("filt", K.Down_F, K.Up_F, True, "Modified UNet: filters around gelu but no filters in up or downsampling"),
+    3: ("filt", K.Down_FFF, K.Up_FFF, True, "Modified UNet: filters around gelu + filters in up or downsampling"),
+    4: ("filt4", K.Down_F4, K.Up_F4, True, "Modified UNet: filters around gelu + filters in up or downsampling + groupnorm"),
+}
+
+
+class UNet(nn.Module):
+    def __init__(self, c_in=3, c_out=3, image_size=64, time_dim=256, device="cuda", f_settings=None,
+                 num_classes=None, variant=0):
+        super().__init__()
+        self.device, self.time_dim, self.image_size, self.f_settings = device, time_dim, image_size, f_settings
+        self.variant = variant
+        if variant not in _VARIANTS:
+            raise ValueError("variant value must be between 0 and 4")
+        kind, mk_down, mk_up, needs_f, banner = _VARIANTS[variant]
+        if needs_f and f_settings is None:
+            raise ValueError("f_settings is empty")
+        print(f"Variant {variant} {banner}")
+
+        fs = {"f_settings": f_settings} if needs_f else {}
+        if kind == "plain":
+            block = lambda i, o: K.DoubleConv(in_channels=i, out_channels=o)
+        elif kind == "filt":
+            block = lambda i, o: K.DoubleConv_F(in_channels=i, out_channels=o, f_settings=f_settings)
+        else:
+            block = lambda i, o: K.DoubleConv_F4(in_channels=i, out_channels=o, f_settings=f_settings)
+        w = int(image_size)                       # channel widths are tied to the image size (:50-84)
+        s = int(image_size)
+        # construction ORDER below is the reference's: it fixes the RNG stream of the seeded init
+        self.inc = block(c_in, w)
+        self.down1 = mk_down(w, 2 * w, **fs)
+        self.sa1 = K.SelfAttention(2 * w, int(s / 2))
+        self.down2 = mk_down(2 * w, 4 * w, **fs)
+        self.sa2 = K.SelfAttention(4 * w, int(s / 4))
+        self.down3 = mk_down(4 * w, 4 * w, **fs)
+        self.sa3 = K.SelfAttention(4 * w, int(s / 8))
+        self.bot1 = block(4 * w, 8 * w)
+        self.bot2 = block(8 * w, 8 * w)
+        self.bot3 = block(8 * w, 4 * w)
+        self.up1 = mk_up(8 * w, 2 * w, **fs)
+        self.sa4 = K.SelfAttention(2 * w, int(s / 4))
+        self.up2 = mk_up(4 * w, w, **fs)
+        self.sa5 = K.SelfAttention(w, int(s / 2))
+        self.up3 = mk_up(2 * w, w, **fs)
+        self.sa6 = K.SelfAttention(w, s)
+        self.outc = nn.Conv2d(w, c_out, kernel_size=1)
+        if num_classes is not None:
+            print("Conditional UNet")
+            self.label_emb = nn.Embedding(num_classes, time_dim)
+        else:
+            print("Unconditional UNet")
+        self._inv_freq = None
+
+    # -- time embedding ---------------------------------------------------------------------
+    def _inv_freq_on(self, device):
+        if self._inv_freq is None or self._inv_freq.device != device:
+            ch = self.time_dim
+            # host-side, in the reference's own fp32 op order, once (ddpm_models.py:262-265)
+            inv = 1.0 / (10000 ** (torch.arange(0, ch, 2).float() / ch))
+            self._inv_freq = inv.to(device)
+        return self._inv_freq
+
+    def pos_encoding(self, t, channels):
+        """t: (B,1) float or (B,) int -> (B, channels) [sin | cos]  (ddpm_models.py:261-269)."""
+        assert channels == self.time_dim
+        tt = t.reshape(-1)
+        if tt.dtype != torch.long:
+            tt = tt.long()
+        return ops.pos_encoding(tt, self._inv_freq_on(tt.device))
+
+    # -- forward ----------------------------------------------------------------------------
+    def forward(self, x, t, y=None):
+        if not x.is_cuda:
+            raise ops.AfdError("afdm.UNet: the HIP engine has no CPU path; move the model and inputs to 'cuda'")
+        t = self.pos_encoding(t.to(x.device), self.time_dim)
+        if y is not None:
+            t = t + self.label_emb(y)
+        x1 = self.inc(x)
+        x2 = self.sa1(self.down1(x1, t))
+        x3 = self.sa2(self.down2(x2, t))
+        x4 = self.sa3(self.down3(x3, t))
+        x4 = self.bot3(self.bot2(self.bot1(x4)))
+        u = self.sa4(self.up1(x4, x3, t))
+        u = self.sa5(self.up2(u, x2, t))
+        u = self.sa6(self.up3(u, x1, t))
+        return ops.conv(u, self.outc.weight, self.outc.bias)

@@ -1,0 +1,175 @@
+/* afd.h -- C ABI of libafd_hip.so: the MI355X (gfx950) engine under the alias-free DDPM hot path.
+ *
+ * The reference (MDFahimAnjum/AliasFree-Diffusion-Models-PyTorch) has no FFI: its hot path is a
+ * plain Python API over torch ATen ops.  Each entry point below names the reference lines whose
+ * device work it replaces (paths relative to the reference root).  The Python host package binds
+ * these with ctypes; nothing here takes or returns a torch type.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (NCHW, contiguous unless a stride is given) except
+ *     where a parameter is documented as HOST (filter taps, shape tables);
+ *   - `stream` is a hipStream_t passed as void*; entry points only enqueue work: they never
+ *     allocate, never synchronise and are legal inside hipGraph stream capture;
+ *   - workspaces are caller-provided; `*_workspace_bytes` tells how much;
+ *   - return value: AFD_OK or an AFD_E* code; afd_last_error() gives the message for this thread.
+ *   - batch strides are in ELEMENTS; 0 means "contiguous" (C*H*W of that tensor).
+ */
+#ifndef AFD_H_
+#define AFD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFD_OK 0
+#define AFD_EINVAL 1     /* null pointer, non-positive size, unsupported shape */
+#define AFD_ELAUNCH 2    /* hip launch / runtime error */
+#define AFD_MAX_TAPS 15  /* largest supported filter side N */
+
+typedef void* afd_stream_t;
+
+const char* afd_version(void);
+const char* afd_last_error(void);
+/* number of HIP devices visible (0 on a CPU-only host); never initialises a context */
+int afd_device_count(void);
+
+/* ---- F1: filter design (HOST code, no GPU) -------------------------------------- filtrs.py:20-37
+ * N x N radial jinc * outer-product Kaiser(beta) window, sum-normalised, fp64 -> fp32.
+ * taps_out: HOST float[N*N].  has_beta = 0 reproduces beta=None. */
+int afd_lowpass_kernel(double omega_c, int N, int has_beta, double beta, float* taps_out);
+
+/* ---- F2: custom_upsample(x, f, factor=2) ---------------------------------------- filtrs.py:79-94
+ * x (B,C,H,W) -> y (B,C,2H,2W).  taps: HOST float[N*N].  *_bwd is the exact adjoint (dx from dy). */
+int afd_filt_up2_fwd(const float* x, float* y, int B, int C, int H, int W, long x_bstride, long y_bstride,
+                     const float* taps, int N, afd_stream_t stream);
+int afd_filt_up2_bwd(const float* dy, float* dx, int B, int C, int H, int W, long dy_bstride, long dx_bstride,
+                     const float* taps, int N, afd_stream_t stream);
+
+/* ---- F3: custom_downsample(x, f, factor=2) -------------------------------------- filtrs.py:71-77
+ * x (B,C,H,W) -> y (B,C,ceil(H/2),ceil(W/2)) (even rows / columns of the filtered image). */
+int afd_filt_down2_fwd(const float* x, float* y, int B, int C, int H, int W, long x_bstride, long y_bstride,
+                       const float* taps, int N, afd_stream_t stream);
+int afd_filt_down2_bwd(const float* dy, float* dx, int B, int C, int H, int W, long dy_bstride, long dx_bstride,
+                       const float* taps, int N, afd_stream_t stream);
+
+/* ---- F4: filtered nonlinearity  y = down2(GELU_erf(up2(v)))  ------------ ddpm_utils.py:123-125,129-131
+ * Optional fused prologue (any pointer may be NULL):
+ *     v[b,c,:,:] = x[b,c,:,:] * (rstd[b]*gamma[c]) + (beta[c] - mean[b]*rstd[b]*gamma[c]) + res[b,c,:,:]
+ * i.e. GroupNorm(1,C)-apply (ddpm_utils.py:122,127) and the residual add (:128) folded into the load.
+ * stats: float[B*2] = {mean, rstd} per sample, or NULL (then gamma/beta are ignored).
+ * workspace: only read when the shape is off the fused fast path (N != 3 or a non-square /
+ * non-power-of-two plane); size from afd_filt_act_workspace_bytes (0 on the fast path).
+ * bwd writes dv = dL/dv (same shape as x); the caller chains dv into GroupNorm-backward / the residual. */
+size_t afd_filt_act_workspace_bytes(int B, int C, int H, int W, int N, int backward);
+int afd_filt_act_fwd(const float* x, float* y, int B, int C, int H, int W,
+                     const float* stats, const float* gamma, const float* beta, const float* res,
+                     const float* taps_up, const float* taps_down, int N,
+                     void* workspace, afd_stream_t stream);
+int afd_filt_act_bwd(const float* x, const float* dy, float* dv, int B, int C, int H, int W,
+                     const float* stats, const float* gamma, const float* beta, const float* res,
+                     const float* taps_up, const float* taps_down, int N,
+                     void* workspace, afd_stream_t stream);
+
+/* ---- F6: nn.GroupNorm(1, C), eps, affine ---------------------------- ddpm_utils.py:85,88,113,116
+ * fwd: stats_out[b] = {mean, rstd}; if y != NULL:
+ *     y = act( gn(x)*gamma + beta + res ) + emb[b,c]
+ *   res  (B,C,H,W) or NULL : residual of DoubleConv (ddpm_utils.py:93);
+ *   act  0 = identity, 1 = exact GELU (nn.GELU, :86 / F.gelu, :93);
+ *   emb  (B,C) or NULL     : time-embedding add of Down/Up (:218-219, :244-245).
+ * bwd: given dy (= dL/dy) recomputes the chain; writes dx, dres (may be NULL), and per-sample
+ *   partials {sum dz*xhat, sum dz} per (b,c) for dgamma/dbeta, which afd_colsum reduces over b.
+ *   The partial buffer must hold B*C*2 + B*2 floats (the tail is scratch).  demb = sum_hw dy is (B,C). */
+int afd_groupnorm1_fwd(const float* x, float* y, float* stats_out, int B, int C, int HW, float eps,
+                       const float* gamma, const float* beta, const float* res, int act, const float* emb,
+                       afd_stream_t stream);
+int afd_groupnorm1_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
+                       const float* gamma, const float* beta, const float* res, int act,
+                       float* dx, float* dres, float* dgamma_dbeta_partial /* B*C*2 + B*2 floats */, float* demb /* (B,C) or NULL */,
+                       afd_stream_t stream);
+/* out[j] (+)= sum_i in[i*cols + j], i < rows (deterministic tree; accumulate != 0 adds into out) */
+int afd_colsum(const float* in, float* out, int rows, int cols, int accumulate, afd_stream_t stream);
+
+/* ---- F5/F10: convolution as implicit GEMM (3x3 pad 1, or 1x1) --------- ddpm_utils.py:84,87,112,115;
+ *      nn.Linear / MHA projections on NCHW tokens (ddpm_utils.py:59-66,71,73); outc (ddpm_models.py:84)
+ * x (B,Cin,H,W), w (Cout,Cin,k,k) k in {1,3}, y (B,Cout,H,W).
+ * epilogue: y = act(conv + bias[co]) + res      (bias/res may be NULL; act 0 none, 1 exact GELU)
+ * dgrad:   dx = conv_transpose(dy, w)           wgrad: dw = sum_b,hw dy (x) x ; dbias = sum dy
+ * wgrad needs a workspace (split-K partials); size from afd_conv_wgrad_workspace_bytes. */
+int afd_conv_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
+                 int B, int Cin, int Cout, int H, int W, int ksize, int act, afd_stream_t stream);
+int afd_conv_dgrad(const float* dy, const float* w, float* dx,
+                   int B, int Cin, int Cout, int H, int W, int ksize, afd_stream_t stream);
+size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ksize);
+int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias /* or NULL */,
+                   int B, int Cin, int Cout, int H, int W, int ksize, int accumulate,
+                   void* workspace, afd_stream_t stream);
+
+/* ---- F10: LayerNorm over channels of an NCHW tensor (= nn.LayerNorm([C]) on (B,L,C) tokens) ------
+ * ddpm_utils.py:60,62,70.  stats_out (B,HW,2) = {mean, rstd}. */
+int afd_layernorm_c_fwd(const float* x, float* y, float* stats_out, int B, int C, int HW, float eps,
+                        const float* gamma, const float* beta, afd_stream_t stream);
+int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
+                        const float* gamma, float* dx, float* dgamma_dbeta_partial /* (B,C,2) */,
+                        afd_stream_t stream);
+
+/* ---- F10: multi-head self-attention core (softmax(QK^T/sqrt(d))V), flash-style ------------------
+ * ddpm_utils.py:71 (nn.MultiheadAttention, batch_first, 4 heads).  qkv (B,3C,L): channel
+ * n = {0:q,1:k,2:v}*C + head*d + j, token index contiguous (the NCHW image of in_proj's output).
+ * o (B,C,L); lse (B,heads,L) saved for backward.  Never materialises the L x L scores. */
+int afd_attn_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d, int L, afd_stream_t stream);
+int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
+                 int B, int heads, int d, int L, afd_stream_t stream);
+
+/* ---- elementwise / pooling used by variants 0 and 2 --------------------------------------------
+ * gelu: nn.GELU (ddpm_utils.py:64); maxpool: nn.MaxPool2d(2) (:203,258);
+ * bilinear: nn.Upsample(scale_factor=2, 'bilinear', align_corners=True) (:226,280). */
+int afd_gelu_fwd(const float* x, float* y, long n, afd_stream_t stream);
+int afd_gelu_bwd(const float* x, const float* dy, float* dx, long n, afd_stream_t stream);
+int afd_maxpool2_fwd(const float* x, float* y, int B, int C, int H, int W, afd_stream_t stream);
+int afd_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int C, int H, int W, afd_stream_t stream);
+int afd_bilinear_up2_fwd(const float* x, float* y, int B, int C, int H, int W, long y_bstride, afd_stream_t stream);
+int afd_bilinear_up2_bwd(const float* dy, float* dx, int B, int C, int H, int W, long dy_bstride, afd_stream_t stream);
+/* strided batch copy: dst[b, 0:n] = src[b, 0:n] (torch.cat of the skip, ddpm_utils.py:242) */
+int afd_copy_batched(const float* src, float* dst, int B, long n, long src_bstride, long dst_bstride, afd_stream_t stream);
+/* y = a + b (gradient accumulation of skip connections) */
+int afd_add(const float* a, const float* b, float* y, long n, afd_stream_t stream);
+
+/* ---- F9: time embedding ------------------------------------- ddpm_models.py:261-269,272-273
+ * temb[b, k] = sin(t[b]*inv_freq[k]), temb[b, half+k] = cos(...); t int64, inv_freq (half,) fp32
+ * (computed once on the host exactly as the reference does).
+ * silu_linear: out[b, n] = sum_k silu(temb[b,k]) * w[n,k] + bias[n]      ddpm_utils.py:208-214 */
+int afd_pos_encoding(const int64_t* t, const float* inv_freq, float* temb, int B, int half, afd_stream_t stream);
+int afd_silu_linear_fwd(const float* temb, const float* w, const float* bias, float* out,
+                        int B, int K, int N, afd_stream_t stream);
+int afd_silu_linear_bwd(const float* temb, const float* w, const float* dout, float* dw, float* dbias,
+                        float* dtemb /* or NULL; accumulated into */, int B, int K, int N, int accumulate, afd_stream_t stream);
+
+/* ---- F14/F16: DDPM noise / denoise / quantise ------------------ ddpm_models.py:317-321, 367-374, 381-385
+ * Bit-exact restatements of the reference's fp32 expression order (no FMA contraction).
+ * t: (B,) int64 indices into the (T,) schedule tables. */
+int afd_noise_images(const float* x, const float* eps, const int64_t* t, const float* alpha_hat,
+                     float* x_t, int B, long per_sample, afd_stream_t stream);
+int afd_denoise_step(const float* x, const float* eps_pred, const float* noise /* NULL => zeros (i == 1) */,
+                     const float* alpha, const float* alpha_hat, const float* beta, int i,
+                     float* x_out, long n, afd_stream_t stream);
+int afd_quantize_u8(const float* x, uint8_t* out, long n, afd_stream_t stream);
+
+/* ---- F15: loss + optimiser ------------------------------------------- ddpm_utils.py:489-490,503-507
+ * mse: loss_out[0] = mean((pred-target)^2) (deterministic two-stage reduction; workspace >= 4096 floats);
+ * mse_bwd: dpred = 2*(pred-target)/n * dloss[0].
+ * adamw: torch.optim.AdamW(lr, betas, eps, weight_decay) over flat fp32 buffers; `state` is
+ * device float[4] {step, bias_corr1, bias_corr2, _} advanced by afd_adamw_tick (graph-replay safe). */
+int afd_mse_fwd(const float* pred, const float* target, float* loss_out, float* workspace, long n, afd_stream_t stream);
+int afd_mse_bwd(const float* pred, const float* target, const float* dloss, float* dpred, long n, afd_stream_t stream);
+int afd_adamw_tick(float* state, float beta1, float beta2, afd_stream_t stream);
+int afd_adamw_step(float* p, const float* g, float* m, float* v, long n, const float* state,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                   afd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFD_H_ */

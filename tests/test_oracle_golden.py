@@ -1,0 +1,179 @@
+"""Pin the CPU oracle (oracle/ref_ops.py) against golden vectors produced by running the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_json, load_golden, rel_l2
+from oracle import ref_ops as R
+
+F_SET = {"kernel_size": 3, "kaiser_beta": 2, "omega_c_down": math.pi / 2, "omega_c_up": math.pi / 2}
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+def test_filter_taps_bit_exact():
+    g = load_golden("filters.npz")
+    for key, omega, N, beta in golden_json(g, "grid"):
+        k = R.lowpass_kernel(omega, N, None if beta < 0 else beta)
+        assert np.array_equal(k.numpy(), g[key]), key
+    k = R.lowpass_kernel(math.pi / 2, 3, 2).numpy()
+    assert abs(k[1, 1] - 0.37743083) < 1e-8 and abs(k[0, 1] - 0.11949231) < 1e-8
+
+
+def test_resample_fwd_bwd():
+    g = load_golden("resample.npz")
+    for tag in golden_json(g, "cases"):
+        x, ku, kd = T(g[f"x_{tag}"]), T(g[f"ku_{tag}"]), T(g[f"kd_{tag}"])
+        for op, fn in (("up", lambda z: R.filt_up2(z, ku)), ("down", lambda z: R.filt_down2(z, ku)),
+                       ("act", lambda z: R.filt_act(z, ku, kd))):
+            xi = x.clone().requires_grad_(True)
+            y = fn(xi)
+            assert y.shape == g[f"{op}_{tag}_y"].shape
+            assert rel_l2(y.detach(), g[f"{op}_{tag}_y"]) < 2e-6, (op, tag)
+            (dx,) = torch.autograd.grad(y, xi, T(g[f"{op}_{tag}_dy"]))
+            assert rel_l2(dx, g[f"{op}_{tag}_dx"]) < 2e-6, (op, tag)
+
+
+def test_n3_closed_form_equals_definition():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, 6, 10, generator=g, dtype=torch.float64)
+    ku = R.lowpass_kernel(math.pi / 2, 3, 2).double()
+    kd = R.lowpass_kernel(math.pi / 3, 3, 1).double()
+    assert rel_l2(R.filt_act_n3_closed_form(x, ku, kd), R.filt_act(x, ku, kd)) < 1e-14
+    # DC gain of the un-compensated upsampler is 1/4
+    one = torch.ones(1, 1, 8, 8, dtype=torch.float64)
+    assert abs(R.filt_up2(one, ku)[0, 0, 3:5, 3:5].mean().item() - 0.25) < 1e-6
+
+
+def _sd(g, prefix):
+    p = prefix + ".sd."
+    return {k[len(p):]: T(g[k]) for k in g.files if k.startswith(p)}
+
+
+BLOCKS = [
+    ("dc_4_8", lambda sd, i, f: R.double_conv(sd, "", i[0], False)),
+    ("dc_res_8", lambda sd, i, f: R.double_conv(sd, "", i[0], True)),
+    ("dc_8_4_mid6", lambda sd, i, f: R.double_conv(sd, "", i[0], False)),
+    ("dcf_4_8", lambda sd, i, f: R.double_conv(sd, "", i[0], False, f)),
+    ("dcf_res_8", lambda sd, i, f: R.double_conv(sd, "", i[0], True, f)),
+    ("sa_8_8", lambda sd, i, f: R.self_attention(sd, "", i[0])),
+    ("sa_16_4", lambda sd, i, f: R.self_attention(sd, "", i[0])),
+    ("down_4_8", lambda sd, i, f: R.down_stage(sd, "", i[0], i[1], 0, None)),
+    ("downF_4_8", lambda sd, i, f: R.down_stage(sd, "", i[0], i[1], 2, f)),
+    ("downFF_4_8", lambda sd, i, f: R.down_stage(sd, "", i[0], i[1], 1, f)),
+    ("downFFF_4_8", lambda sd, i, f: R.down_stage(sd, "", i[0], i[1], 3, f)),
+    ("up_8_4", lambda sd, i, f: R.up_stage(sd, "", i[0], i[1], i[2], 0, None)),
+    ("upF_8_4", lambda sd, i, f: R.up_stage(sd, "", i[0], i[1], i[2], 2, f)),
+    ("upFF_8_4", lambda sd, i, f: R.up_stage(sd, "", i[0], i[1], i[2], 1, f)),
+    ("upFFF_8_4", lambda sd, i, f: R.up_stage(sd, "", i[0], i[1], i[2], 3, f)),
+]
+
+
+@pytest.mark.parametrize("name,fn", BLOCKS, ids=[b[0] for b in BLOCKS])
+def test_blocks_fwd_bwd(name, fn):
+    g = load_golden("blocks.npz")
+    k = R.lowpass_kernel(math.pi / 2, 3, 2)
+    sd = {kk: v.clone().requires_grad_(True) for kk, v in _sd(g, name).items()}
+    ins = []
+    j = 0
+    while f"{name}.in{j}" in g.files:
+        ins.append(T(g[f"{name}.in{j}"]).clone().requires_grad_(True))
+        j += 1
+    y = fn(sd, ins, (k, k))
+    assert rel_l2(y.detach(), g[f"{name}.y"]) < 3e-6
+    names = list(sd.keys())
+    grads = torch.autograd.grad(y, ins + [sd[n] for n in names], T(g[f"{name}.dy"]), allow_unused=True)
+    for j in range(len(ins)):
+        assert rel_l2(grads[j], g[f"{name}.din{j}"]) < 2e-5, (name, j)
+    for n, gr in zip(names, grads[len(ins):]):
+        key = f"{name}.dsd.{n}"
+        assert rel_l2(gr, g[key]) < 2e-5, key
+
+
+def _init_like_reference(variant, c):
+    """The oracle needs the reference's seeded weights; the product package reproduces the
+    reference's construction order, so build through it and verify by checksum."""
+    import afdm
+    afdm.set_seed(42)
+    net = afdm.UNet(c_in=c, c_out=c, image_size=32, f_settings=dict(F_SET) if variant else None,
+                    device="cpu", variant=variant)
+    return net
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("c", [1, 3])
+def test_unet_forward_matches_reference(variant, c):
+    g = load_golden("unet_fwd.npz")
+    tag = f"v{variant}_c{c}"
+    net = _init_like_reference(variant, c)
+    sd = net.state_dict()
+    meta = golden_json(g, "meta")[tag]
+    assert list(sd.keys()) == meta["keys"]
+    cs = np.array([[v.double().sum().item(), v.double().abs().sum().item()] for v in sd.values()])
+    assert np.allclose(cs, g[f"{tag}.param_checksums"], rtol=0, atol=0), "seeded init differs from the reference"
+    x, t = T(g[f"{tag}.x"]), T(g[f"{tag}.t"])
+    assert np.array_equal(R.time_embedding(t).numpy(), g[f"{tag}.posenc"])
+    with torch.no_grad():
+        y = R.unet_forward(sd, x, t, variant, F_SET)
+    assert rel_l2(y, g[f"{tag}.y"]) < 5e-6
+
+
+def test_schedule_bit_exact():
+    g = load_golden("schedule.npz")
+    for Tn in (1000, 300, 101, 11):
+        b, a, ah = R.noise_schedule(Tn)
+        assert np.array_equal(b.numpy(), g[f"beta_{Tn}"])
+        assert np.array_equal(a.numpy(), g[f"alpha_{Tn}"])
+        assert np.array_equal(ah.numpy(), g[f"alpha_hat_{Tn}"])
+    _, _, ah = R.noise_schedule(1000)
+    xt = R.noise_images(ah, T(g["noise_x"]), T(g["noise_t"]), T(g["noise_eps"]))
+    assert np.array_equal(xt.numpy(), g["noise_xt"])
+    assert list(g["t_seed42_n8"]) == [790, 618, 251, 50, 64, 435, 413, 942]
+
+
+def test_train_step_loss_and_grads():
+    g = load_golden("train_step.npz")
+    net = _init_like_reference(3, 3)
+    sd = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    _, _, ah = R.noise_schedule(1000)
+    loss, pred, grads = R.train_step_loss_and_grads(sd, T(g["images"]), T(g["t0"]), T(g["eps0"]), 3, F_SET, ah)
+    assert abs(loss.item() - g["losses"][0]) < 1e-5 * abs(g["losses"][0])
+    assert rel_l2(pred, g["pred0"]) < 5e-6
+    for key in g.files:
+        if key.startswith("grad0."):
+            assert rel_l2(grads[key[6:]], g[key]) < 1e-4, key
+    names = [n for n, _ in net.named_parameters()]
+    l2 = np.array([grads[n].double().pow(2).sum().sqrt().item() for n in names])
+    assert np.allclose(l2, g["grad_checksums0"][:, 2], rtol=2e-4, atol=1e-9)
+    # AdamW restatement against the reference's post-step parameters
+    for key in g.files:
+        if key.startswith("param1."):
+            n = key[7:]
+            p1, _, _ = R.adamw_step(sd[n].detach(), T(g["grad0." + n]) if "grad0." + n in g.files else grads[n],
+                                    torch.zeros_like(sd[n]), torch.zeros_like(sd[n]), 1, 3e-4)
+            assert rel_l2(p1, g[key]) < 1e-6, key
+
+
+def test_sample_loop_quantised_and_float():
+    g = load_golden("sample.npz")
+    net = _init_like_reference(0, 1)
+    sd = net.state_dict()
+    import afdm
+    afdm.set_seed(7)
+    with torch.no_grad():
+        xf, xq, rq = R.sample_loop(lambda x, t: R.unet_forward(sd, x, t, 0, None), 101, 2, 1, 32)
+    assert rel_l2(xf, g["v0_c1.float_x_after_i1"]) < 1e-4
+    assert rq.shape == g["v0_c1.sample_result"].shape == (4, 1, 32, 32)
+    mism = (xq.numpy().astype(int) - g["v0_c1.sample_x"].astype(int))
+    assert np.abs(mism).max() <= 1 and (mism != 0).mean() < 0.01
+
+
+def test_quantise_and_rotate():
+    g = load_golden("sample.npz")
+    x = torch.tensor([-1.5, -1.0, -0.999, 0.0, 0.5, 0.9999, 1.0, 2.0])
+    assert R.quantize_u8(x).tolist() == [0, 0, 0, 127, 191, 254, 255, 255]
+    m = T(g["rot_in"])
+    for ai in range(4):
+        assert np.array_equal(R.rotate_wrap(m, float(g[f"rot_angle_{ai}"])).numpy(), g[f"rot_out_{ai}"])
