@@ -4,7 +4,7 @@
 // Layout: qkv (B, 3C, L) = the NCHW image of the in-projection, channel = {q,k,v}*C + head*d + j,
 // token index contiguous; o (B, C, L); lse (B, heads, L).
 //
-// Shapes here are d in {8,16,32,64}, L in {16..4096}: with d = 8 a 32x32 or 16x16 MFMA tile would
+// Shapes here are d in {2,4,8,16,32,64}, L in {16..4096}: with d = 8 a 32x32 or 16x16 MFMA tile would
 // run 50-75 % empty and the exp / max / rescale work (VALU) is as large as the contractions, so
 // the kernels are one-lane-per-row VALU kernels: the lane keeps its query (or key) row, the output
 // accumulator and the running max / sum in registers; the other operand streams through LDS in
@@ -199,6 +199,8 @@ using namespace afd;
 
 #define AFD_ATTN_DISPATCH(D_, KERNEL, ...)                                                     \
   switch (D_) {                                                                                \
+    case 2:  hipLaunchKernelGGL(KERNEL<2>,  grid, dim3(kAttnBlock), 0, s, __VA_ARGS__); break; \
+    case 4:  hipLaunchKernelGGL(KERNEL<4>,  grid, dim3(kAttnBlock), 0, s, __VA_ARGS__); break; \
     case 8:  hipLaunchKernelGGL(KERNEL<8>,  grid, dim3(kAttnBlock), 0, s, __VA_ARGS__); break; \
     case 16: hipLaunchKernelGGL(KERNEL<16>, grid, dim3(kAttnBlock), 0, s, __VA_ARGS__); break; \
     case 32: hipLaunchKernelGGL(KERNEL<32>, grid, dim3(kAttnBlock), 0, s, __VA_ARGS__); break; \
@@ -209,7 +211,7 @@ extern "C" {
 
 int afd_attn_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d, int L, afd_stream_t st) {
   AFD_REQUIRE(qkv && o && lse && B > 0 && heads > 0 && L > 0, "afd_attn_fwd: bad argument");
-  AFD_REQUIRE(d == 8 || d == 16 || d == 32 || d == 64, "afd_attn_fwd: head dim %d not in {8,16,32,64}", d);
+  AFD_REQUIRE(d == 2 || d == 4 || d == 8 || d == 16 || d == 32 || d == 64, "afd_attn_fwd: head dim %d not in {2,4,8,16,32,64}", d);
   AFD_REQUIRE(B <= 65535 && heads <= 65535, "afd_attn_fwd: grid too large");
   hipStream_t s = as_stream(st);
   const dim3 grid((L + kAttnBlock - 1) / kAttnBlock, heads, B);
@@ -221,7 +223,7 @@ int afd_attn_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d
 int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                  int B, int heads, int d, int L, afd_stream_t st) {
   AFD_REQUIRE(qkv && o && d_o && lse && dqkv && B > 0 && heads > 0 && L > 0, "afd_attn_bwd: bad argument");
-  AFD_REQUIRE(d == 8 || d == 16 || d == 32 || d == 64, "afd_attn_bwd: head dim %d not in {8,16,32,64}", d);
+  AFD_REQUIRE(d == 2 || d == 4 || d == 8 || d == 16 || d == 32 || d == 64, "afd_attn_bwd: head dim %d not in {2,4,8,16,32,64}", d);
   AFD_REQUIRE(B <= 65535 && heads <= 65535, "afd_attn_bwd: grid too large");
   hipStream_t s = as_stream(st);
   const dim3 grid((L + kAttnBlock - 1) / kAttnBlock, heads, B);

@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""bench.py -- train-step images/sec (+ sample images/sec) of the Config-D UNet on MI355X.
+
+Workload (BASELINE.json configs[2]/[3]): CIFAR-10-shaped synthetic batches 3x32x32, UNet variant=3
+(filtered GELU + filtered resampling, f_settings {3, 2, pi/2, pi/2}), 256 images per GPU, T=1000,
+lr 3e-4, fp32.  One "step" = the reference's per-batch body (ddpm_utils.py:499-507): timestep draw,
+noise_images, UNet forward, MSE, backward, [gradient all-reduce], AdamW.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Extra objects: `roofline` (dominant kernel, timed live with HIP events
+on the launch stream), `kernels` (every kernel family timed the same way), `cpu_baseline`
+(the CPU oracle's train step on the host cores, bounded sample), `sample` (Diffusion.sample).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+F_SET = {"kernel_size": 3, "kaiser_beta": 2, "omega_c_down": math.pi / 2, "omega_c_up": math.pi / 2}
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+
+# Config D layer table: (Cin, Cout, HW side) of every 3x3 conv, forward order
+CONV3 = ([(3, 32, 32), (32, 32, 32)] + [(32, 32, 16)] * 2 + [(32, 64, 16), (64, 64, 16)] + [(64, 64, 8)] * 2 +
+         [(64, 128, 8), (128, 128, 8)] + [(128, 128, 4)] * 4 + [(128, 256, 4), (256, 256, 4), (256, 256, 4), (256, 256, 4),
+         (256, 128, 4), (128, 128, 4)] + [(256, 256, 8)] * 2 + [(256, 128, 8), (128, 64, 8)] + [(128, 128, 16)] * 2 +
+         [(128, 64, 16), (64, 32, 16)] + [(64, 64, 32)] * 2 + [(64, 32, 32), (32, 32, 32)])
+# filtered-GELU sites (C, side)
+ACT_SITES = ([(32, 32)] + [(32, 16)] * 2 + [(64, 16)] + [(64, 8)] * 2 + [(128, 8)] + [(128, 4)] * 3 + [(256, 4), (256, 4), (128, 4)] +
+             [(256, 8)] * 2 + [(128, 8)] + [(128, 16)] * 2 + [(64, 16)] + [(64, 32)] * 2 + [(32, 32)])
+ATTN = [(64, 16), (128, 8), (128, 4), (64, 8), (32, 16), (32, 32)]      # (C, side), 4 heads
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """CPU threads this process may really use (cgroup / affinity aware), capped at 16 = one GPU's share."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def ev_time(fn, reps=5, warm=2):
+    """Average device time of fn() in ms, HIP events on the current (= launch) stream."""
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def kernel_table(dev, B):
+    """Times each kernel family over the Config-D shapes of one train step (forward + backward)."""
+    import afdm
+    from afdm import ops
+    L, s = afdm.lib(), torch.cuda.current_stream().cuda_stream
+    rows = {}
+
+    def add(name, ms, flops=0.0, bytes_=0.0, launches=1):
+        r = rows.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+        r["ms"] += ms; r["flops"] += flops; r["bytes"] += bytes_; r["launches"] += launches
+
+    seen = {}
+    for (ci, co, S) in CONV3:
+        key = (ci, co, S)
+        if key not in seen:
+            x = torch.randn(B, ci, S, S, device=dev); w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+            y = torch.empty(B, co, S, S, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
+            ws = torch.empty(max(L.afd_conv_wgrad_workspace_bytes(B, ci, co, S, S, 3) // 4, 1), device=dev)
+            tf = ev_time(lambda: L.afd_conv_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 3, 0, s))
+            td = ev_time(lambda: L.afd_conv_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), B, ci, co, S, S, 3, s)) if ci > 3 else 0.0
+            tw = ev_time(lambda: L.afd_conv_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, B, ci, co, S, S, 3, 0, ws.data_ptr(), s))
+            seen[key] = (tf, td, tw)
+            del x, w, y, dx, dw, ws
+        tf, td, tw = seen[key]
+        fl = 2.0 * B * S * S * ci * co * 9
+        kind = "conv3x3_fwd_mfma" if ci >= 8 else "conv3x3_fwd_direct"
+        add(kind, tf, fl)
+        if ci > 3:
+            add("conv3x3_dgrad_mfma", td, fl)
+        add("conv3x3_wgrad_mfma", tw, fl)
+    seen = {}
+    k = afdm.circularLowpassKernel(math.pi / 2, 3, 2)
+    tk = ops.Taps(k)
+    for (C, S) in ACT_SITES:
+        if (C, S) not in seen:
+            x = torch.randn(B, C, S, S, device=dev); y = torch.empty_like(x); dv = torch.empty_like(x)
+            st = torch.zeros(B, 2, device=dev); st[:, 1] = 1
+            g = torch.ones(C, device=dev); be = torch.zeros(C, device=dev)
+            tf = ev_time(lambda: L.afd_filt_act_fwd(x.data_ptr(), y.data_ptr(), B, C, S, S, st.data_ptr(), g.data_ptr(), be.data_ptr(), None, tk.ptr, tk.ptr, 3, None, s))
+            tb = ev_time(lambda: L.afd_filt_act_bwd(x.data_ptr(), y.data_ptr(), dv.data_ptr(), B, C, S, S, st.data_ptr(), g.data_ptr(), be.data_ptr(), None, tk.ptr, tk.ptr, 3, None, s))
+            tg = ev_time(lambda: L.afd_groupnorm1_fwd(x.data_ptr(), None, st.data_ptr(), B, C, S * S, 1e-5, None, None, None, 0, None, s))
+            seen[(C, S)] = (tf, tb, tg)
+            del x, y, dv
+        tf, tb, tg = seen[(C, S)]
+        e = float(B) * C * S * S
+        add("filt_act_fwd_n3", tf, bytes_=8 * e)
+        add("filt_act_bwd_n3", tb, bytes_=12 * e)
+        add("groupnorm1_stats", tg, bytes_=4 * e)
+    for (C, S) in ATTN:
+        Lq = S * S
+        qkv = torch.randn(B, 3 * C, S, S, device=dev); o = torch.empty(B, C, S, S, device=dev)
+        lse = torch.empty(B, 4, Lq, device=dev); dq = torch.empty_like(qkv)
+        tf = ev_time(lambda: L.afd_attn_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, 4, C // 4, Lq, s), reps=3, warm=1)
+        tb = ev_time(lambda: L.afd_attn_bwd(qkv.data_ptr(), o.data_ptr(), o.data_ptr(), lse.data_ptr(), dq.data_ptr(), B, 4, C // 4, Lq, s), reps=3, warm=1)
+        fl = 4.0 * B * Lq * Lq * C
+        add("attn_fwd", tf, fl)
+        add("attn_bwd", tb, 2.5 * fl, launches=2)
+        del qkv, o, lse, dq
+    torch.cuda.synchronize()
+    out = []
+    for name, r in rows.items():
+        sec = r["ms"] * 1e-3
+        out.append({"kernel": name, "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 4),
+                    "tflops": round(r["flops"] / sec / 1e12, 3) if r["flops"] else None,
+                    "gbs": round(r["bytes"] / sec / 1e9, 1) if r["bytes"] else None})
+    return out, rows
+
+
+def cpu_baseline(steps=2, B=16):
+    """The CPU oracle's train step (fwd + autograd bwd + AdamW) on the host cores, Config D, B=16."""
+    import afdm
+    from oracle import ref_ops as R
+    torch.set_num_threads(host_threads())
+    afdm.set_seed(42)
+    net = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device="cpu", variant=3)
+    sd = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
+    _, _, ah = R.noise_schedule(1000)
+    g = torch.Generator().manual_seed(42)
+    images = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        t = torch.randint(1, 1000, (B,))
+        eps = torch.randn(images.shape)
+        _, _, grads = R.train_step_loss_and_grads(sd, images, t, eps, 3, F_SET, ah)
+        with torch.no_grad():
+            for kname in sd:
+                p, m[kname], v2[kname] = R.adamw_step(sd[kname], grads[kname], m[kname], v2[kname], it + 1, 3e-4)
+                sd[kname].copy_(p)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / steps
+    return {"value": round(B / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"CPU oracle (oracle/ref_ops.py, torch-CPU fp32) train step, Config D, B={B}, {steps} timed steps after 1 warm-up, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--variant", type=int, default=3)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-sample", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--sample-n", type=int, default=256)
+    ap.add_argument("--sample-steps", type=int, default=1000, help="noise_steps T of the sampling run (999 forwards at 1000)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import afdm
+    afdm.lib()                                    # raises if libafd_hip.so is missing: no fallback
+    afdm.set_seed(42)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET) if args.variant else None,
+                          device=dev, variant=args.variant).to(dev)
+    diff = afdm.Diffusion(noise_steps=1000, img_size=32, device=dev)
+    use_graph = (world == 1) and not args.no_graph
+    step = afdm.TrainStep(model, diff, lr=3e-4, graph=use_graph, distributed=(world > 1))
+    g = torch.Generator().manual_seed(42 + rank)
+    images = (torch.rand(args.batch, 3, 32, 32, generator=g) * 2 - 1).to(dev)
+    torch.manual_seed(42 + rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    graph_ok = use_graph
+    log(f"rank {rank}/{world}: model ready, warm-up ({'hipGraph' if use_graph else 'eager'})")
+    try:
+        for _ in range(args.warmup):
+            loss = step(images)
+    except Exception as e:                        # capture failure: report it and fall back to eager launches
+        if not use_graph:
+            raise
+        print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+        graph_ok = False
+        step = afdm.TrainStep(model, diff, lr=3e-4, graph=False, distributed=False)
+        for _ in range(args.warmup):
+            loss = step(images)
+    sync()
+    log("timing train steps")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(images)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    final_loss = float(loss.item())
+    ms = dt / args.steps * 1e3
+    value = args.batch * world / (dt / args.steps)
+
+    result = {
+        "metric": "train_step_images_per_sec", "value": round(value, 1), "unit": "images/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"CIFAR-10 32x32x3 synthetic, UNet variant={args.variant} (Config {'ABCDE'[args.variant]}), "
+                               f"batch {args.batch}/GPU, T=1000, AdamW lr 3e-4, random-init weights (seed 42)",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": graph_ok},
+        "final_loss": round(final_loss, 5),
+    }
+
+    log(f"train: {ms:.2f} ms/step, {value:.0f} img/s, loss {final_loss:.4f}")
+    if not args.no_sample:
+        log("sampling")
+        n = args.sample_n
+        ds = afdm.Diffusion(noise_steps=args.sample_steps, img_size=32, device=dev)
+        sync()
+        t0 = time.perf_counter()
+        xq, _ = ds.sample(model, n=n, image_channels=3, noise_source="device")
+        sync()
+        sdt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([sdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sdt = tt.item()
+        result["sample"] = {"metric": "sample_images_per_sec", "value": round(n * world / sdt, 3), "unit": "images/s",
+                            "n_per_gpu": n, "denoise_steps": args.sample_steps - 1, "seconds": round(sdt, 3)}
+
+    if rank == 0 and world == 1:
+        if not args.no_kernels:
+            log("per-kernel timing")
+            table, rows = kernel_table(dev, args.batch)
+            dom = max(rows.items(), key=lambda kv: kv[1]["ms"])
+            name, r = dom
+            sec = r["ms"] * 1e-3
+            if r["flops"]:
+                ach = r["flops"] / sec / 1e12
+                result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF,
+                                      "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                                      "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3)}
+            else:
+                ach = r["bytes"] / sec / 1e9
+                result["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                      "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3)}
+            result["kernels"] = table
+        if not args.no_cpu_baseline:
+            log(f"CPU baseline on {host_threads()} host threads")
+            result["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -237,6 +237,20 @@ def gen_schedule(rm, rutil):
     t = d.sample_timesteps(8)
     x_t, eps = d.noise_images(x, t)
     out["noise_x"], out["noise_t"], out["noise_xt"], out["noise_eps"] = n(x), n(t), n(x_t), n(eps)
+    # one denoise update (ddpm_models.py:367-374) per step-index class, with fixed inputs.  The
+    # expression below is the reference's line :374 verbatim in meaning; gen_sample() checks that
+    # replaying it reproduces Diffusion.sample()'s own uint8 output.
+    g = torch.Generator().manual_seed(8)
+    xx, ee, nz = (torch.randn(2, 3, 8, 8, generator=g) for _ in range(3))
+    out["den_x"], out["den_eps"], out["den_noise"] = n(xx), n(ee), n(nz)
+    for i in (999, 500, 2, 1):
+        tt = (torch.ones(2) * i).long()
+        a, ah, b = d.alpha[tt][:, None, None, None], d.alpha_hat[tt][:, None, None, None], d.beta[tt][:, None, None, None]
+        noise = nz if i > 1 else torch.zeros_like(xx)
+        out[f"den_out_{i}"] = n(1 / torch.sqrt(a) * (xx - ((1 - a) / (torch.sqrt(1 - ah))) * ee) + torch.sqrt(b) * noise)
+    v = torch.cat([torch.linspace(-1.5, 1.5, 100001), torch.tensor([-1.0, 1.0, 0.0, 0.999999, -0.999999])])
+    out["quant_in"] = n(v)
+    out["quant_out"] = n(((v.clamp(-1, 1) + 1) / 2 * 255).type(torch.uint8))
     save("schedule.npz", **out)
 
 
@@ -318,6 +332,8 @@ def gen_sample(rm, rutil):
             model.train()
         for i, v in traj.items():
             out[f"{tag}.float_x_after_i{i}"] = n(v)
+        hand = (((xx.clamp(-1, 1) + 1) / 2) * 255).type(torch.uint8)
+        assert torch.equal(hand, x), "hand replay of ddpm_models.py:367-374 diverged from Diffusion.sample"
         # rotation (Config E) on the same model: theta=90 over T=101 -> 100 rotations of 90/101 deg
         if variant == 3:
             rutil.set_seed(7)

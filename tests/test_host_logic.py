@@ -1,0 +1,114 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/afd.h declares, the
+host-side entry point (filter design) is bit-exact vs the reference, the module shells reproduce the
+reference's state_dict / seeded init, and the N>1 data-parallel plumbing works (gloo, world_size 2)."""
+import ctypes
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_json, load_golden
+
+F_SET = {"kernel_size": 3, "kaiser_beta": 2, "omega_c_down": math.pi / 2, "omega_c_up": math.pi / 2}
+
+
+def test_library_exports_every_declared_symbol():
+    import afdm
+    from afdm._lib import LIBPATH, parse_header
+    sigs = parse_header()
+    assert len(sigs) >= 40
+    cdll = ctypes.CDLL(LIBPATH)
+    for name in sigs:
+        assert hasattr(cdll, name), f"{name} declared in include/afd.h but not exported"
+    assert afdm.lib().afd_version().startswith(b"afd-hip")
+
+
+def test_entry_points_reject_bad_arguments_without_a_gpu():
+    import afdm
+    L = afdm.lib()
+    with pytest.raises(afdm.AfdError, match="N=99"):
+        L.afd_lowpass_kernel(1.0, 99, 0, 0.0, np.empty(4, dtype=np.float32).ctypes.data)
+    with pytest.raises(afdm.AfdError, match="NULL"):
+        L.afd_filt_up2_fwd(None, None, 1, 1, 4, 4, 0, 0, None, 3, None)
+    with pytest.raises(afdm.AfdError, match="ksize"):
+        L.afd_conv_fwd(1, 1, None, None, 1, 1, 8, 8, 4, 4, 5, 0, None)
+
+
+def test_filter_design_in_the_library_is_bit_exact_vs_reference():
+    import afdm
+    g = load_golden("filters.npz")
+    for key, omega, N, beta in golden_json(g, "grid"):
+        k = afdm.circularLowpassKernel(omega, N, None if beta < 0 else beta)
+        assert k.dtype == torch.float32 and np.array_equal(k.numpy(), g[key]), key
+    k = afdm.circularLowpassKernel(omega_c=math.pi / 2, N=3, beta=2).numpy()
+    assert abs(k.sum() - 1.0) < 1e-6 and abs(k[1, 1] - 0.37743083) < 1e-8
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_state_dict_and_seeded_init_match_reference(variant):
+    import afdm
+    g = load_golden("unet_fwd.npz")
+    meta = golden_json(g, "meta")
+    for c in ((1, 3) if variant < 4 else (3,)):
+        tag = f"v{variant}_c{c}"
+        afdm.set_seed(42)
+        net = afdm.UNet(c_in=c, c_out=c, image_size=32, f_settings=dict(F_SET) if variant else None, device="cpu", variant=variant)
+        sd = net.state_dict()
+        assert list(sd.keys()) == meta[tag]["keys"]
+        assert [list(v.shape) for v in sd.values()] == meta[tag]["shapes"]
+        assert sum(p.numel() for p in net.parameters()) == meta[tag]["n_params"]
+        cs = np.array([[v.double().sum().item(), v.double().abs().sum().item()] for v in sd.values()])
+        assert np.allclose(cs, g[f"{tag}.param_checksums"], rtol=1e-12, atol=1e-12)
+    assert meta["v3_c1"]["n_params"] == 5896513 and meta["v3_c3"]["n_params"] == 5897155     # Results.ipynb:121
+
+
+def test_constructor_contract_and_loud_cpu_failure():
+    import afdm
+    with pytest.raises(ValueError, match="f_settings is empty"):
+        afdm.UNet(variant=3)
+    with pytest.raises(ValueError, match="variant value must be between 0 and 4"):
+        afdm.UNet(variant=5)
+    net = afdm.UNet(c_in=1, c_out=1, image_size=32, device="cpu", variant=0)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        net(torch.randn(2, 1, 32, 32), torch.tensor([500, 500]))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        afdm.custom_upsample(torch.randn(1, 1, 4, 4), afdm.circularLowpassKernel(1.0, 3))
+
+
+def test_schedule_and_timesteps_bit_exact_on_host():
+    import afdm
+    g = load_golden("schedule.npz")
+    for T in (1000, 300, 101, 11):
+        d = afdm.Diffusion(noise_steps=T, img_size=32, device="cpu")
+        assert np.array_equal(d.beta.numpy(), g[f"beta_{T}"])
+        assert np.array_equal(d.alpha.numpy(), g[f"alpha_{T}"])
+        assert np.array_equal(d.alpha_hat.numpy(), g[f"alpha_hat_{T}"])
+    d = afdm.Diffusion(noise_steps=1000, img_size=32, device="cpu")
+    afdm.set_seed(42)
+    assert d.sample_timesteps(8).tolist() == [790, 618, 251, 50, 64, 435, 413, 942]
+    afdm.set_seed(42)
+    assert np.array_equal(d.sample_timesteps(256).numpy(), g["t_seed42_n256"])
+
+
+def test_modules_shim_resolves_reference_import_paths():
+    sys.path.insert(0, ROOT)
+    from modules.ddpm_models import UNet, Diffusion          # Results.ipynb:33-39
+    from modules.ddpm_utils import train, argument, DoubleConv_F, Down_FFF, SelfAttention   # noqa: F401
+    from modules.filtrs import circularLowpassKernel, custom_upsample, custom_downsample     # noqa: F401
+    from modules.utils import set_seed, setup_logging                                      # noqa: F401
+    import afdm
+    assert UNet is afdm.UNet and Diffusion is afdm.Diffusion
+
+
+def test_two_rank_gloo_gradient_exchange(tmp_path):
+    out = tmp_path / "ddp_cpu.pt"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", PYTHONPATH=ROOT, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(ROOT, "tests", "ddp_worker.py"), "--device", "cpu", "--out", str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=300)
+    res = torch.load(out, weights_only=True)
+    assert res["ok"] and res["world"] == 2
