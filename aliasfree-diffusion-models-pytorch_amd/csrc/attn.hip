@@ -4,208 +4,270 @@
 // Layout: qkv (B, 3C, L) = the NCHW image of the in-projection, channel = {q,k,v}*C + head*d + j,
 // token index contiguous; o (B, C, L); lse (B, heads, L).
 //
-// Shapes here are d in {2,4,8,16,32,64}, L in {16..4096}: with d = 8 a 32x32 or 16x16 MFMA tile would
-// run 50-75 % empty and the exp / max / rescale work (VALU) is as large as the contractions, so
-// the kernels are one-lane-per-row VALU kernels: the lane keeps its query (or key) row, the output
-// accumulator and the running max / sum in registers; the other operand streams through LDS in
-// tiles that every lane reads at the same address (LDS broadcast, conflict-free).
-// Forward: lane = query.  Backward: one pass with lane = query (dQ), one with lane = key (dK, dV);
-// delta = rowsum(dO * O) is recomputed per tile -- no atomics, bitwise reproducible.
+// Shapes here are d in {2,4,8,16,32,64}, L in {16..4096}.  With d = 8 an MFMA tile would run 50-75 %
+// empty and the exp / max / rescale work is as large as the contractions, so these are VALU kernels:
+// a lane owns R query (or key) rows -- their vectors, accumulators and running max / sum live in
+// registers -- while the other operand streams through LDS in 64-row tiles stored [row][d], read with
+// ONE ds_read_b128 per 4 values at a wave-uniform address (broadcast, conflict-free) and reused by
+// all R rows of the lane.  History (profiles/): v1 read the tile with 16 ds_read_b32 per key and one
+// row per lane -> LDS-issue bound (1.4 ms fwd / 3.5 ms bwd per step); v2 used wave-uniform scalar
+// loads -> SGPR-bound backward (5.8 ms).  R rows per lane cut the LDS traffic per (q,k) pair by 4R.
+// Forward: lane = query rows.  Backward: pass 1 lane = query rows (dQ, stores delta = rowsum(dO*O)),
+// pass 2 lane = key rows (dK, dV) -- no atomics, bitwise reproducible.
 #include "common.h"
 
 namespace afd {
 
-constexpr int kTile = 64;     // keys (or queries) staged per LDS tile
-constexpr int kAttnBlock = 128;
+constexpr int kTile = 64;      // rows of the streamed operand per LDS tile
+constexpr int kChunk = 8;      // keys per online-softmax rescale
 
-template <int D>
-__global__ __launch_bounds__(kAttnBlock) void attn_fwd_k(const float* __restrict__ qkv, float* __restrict__ o,
-                                                         float* __restrict__ lse, int heads, int L, float scale) {
-  __shared__ float Ks[D][kTile];
-  __shared__ float Vs[D][kTile];
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int C = heads * D;
-  const int qi = blockIdx.x * kAttnBlock + threadIdx.x;
-  const bool live = qi < L;
-  const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
-  const float* kp = qp + (long)C * L;
-  const float* vp = kp + (long)C * L;
-  float q[D], acc[D];
+template <int D> struct RowVec {                 // one [d] row in LDS, read as b128 / b64 broadcasts
+  static __device__ __forceinline__ void load(const float* __restrict__ p, float (&v)[D]) {
+    if constexpr (D % 4 == 0) {
 #pragma unroll
-  for (int j = 0; j < D; ++j) { q[j] = live ? qp[(long)j * L + qi] * scale : 0.f; acc[j] = 0.f; }
-  float m = -INFINITY, l = 0.f;
-  for (int k0 = 0; k0 < L; k0 += kTile) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < D * kTile; i += kAttnBlock) {
-      const int j = i / kTile, kk = i % kTile;
-      const bool in = k0 + kk < L;
-      Ks[j][kk] = in ? kp[(long)j * L + k0 + kk] : 0.f;
-      Vs[j][kk] = in ? vp[(long)j * L + k0 + kk] : 0.f;
-    }
-    __syncthreads();
-    const int nk = min(kTile, L - k0);
-    for (int c0 = 0; c0 < nk; c0 += 8) {            // chunks of 8 keys: one rescale per chunk
-      float s[8];
-      float cm = m;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        float a = 0.f;
-#pragma unroll
-        for (int j = 0; j < D; ++j) a += q[j] * Ks[j][c0 + u];
-        s[u] = (c0 + u < nk) ? a : -INFINITY;
-        cm = fmaxf(cm, s[u]);
+      for (int j = 0; j < D / 4; ++j) {
+        const float4 t = reinterpret_cast<const float4*>(p)[j];
+        v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
       }
-      const float alpha = __expf(m - cm);            // m = -inf on the first chunk -> 0
-      l *= alpha;
-#pragma unroll
-      for (int j = 0; j < D; ++j) acc[j] *= alpha;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float p = __expf(s[u] - cm);
-        l += p;
-#pragma unroll
-        for (int j = 0; j < D; ++j) acc[j] += p * Vs[j][c0 + u];
-      }
-      m = cm;
+    } else {
+      const float2 t = *reinterpret_cast<const float2*>(p);
+      v[0] = t.x; v[1] = t.y;
     }
   }
-  if (live) {
-    const float inv = 1.0f / l;
-    float* op = o + ((long)b * C + h * D) * L + qi;
-#pragma unroll
-    for (int j = 0; j < D; ++j) op[(long)j * L] = acc[j] * inv;
-    lse[((long)b * heads + h) * L + qi] = m + __logf(l);
+};
+
+// stage rows [r0, r0+kTile) of a (D, L) j-major operand into LDS as [row][D] (optionally scaled)
+template <int D>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ src, float* __restrict__ dst, int r0, int L, float mul) {
+  for (int i = threadIdx.x; i < D * kTile; i += blockDim.x) {
+    const int j = i / kTile, rr = i % kTile;
+    dst[rr * D + j] = (r0 + rr < L) ? src[(long)j * L + r0 + rr] * mul : 0.f;
   }
 }
 
-// dQ: lane = query.  ds = p * (dp - delta) ; dq += ds * k * scale
-template <int D>
-__global__ __launch_bounds__(kAttnBlock) void attn_bwd_dq_k(const float* __restrict__ qkv, const float* __restrict__ o,
-                                                            const float* __restrict__ d_o, const float* __restrict__ lse,
-                                                            float* __restrict__ dqkv, int heads, int L, float scale) {
-  __shared__ float Ks[D][kTile];
-  __shared__ float Vs[D][kTile];
+template <int D, int R>
+__global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv, float* __restrict__ o,
+                                                  float* __restrict__ lse, int heads, int L, float scale) {
+  __shared__ __attribute__((aligned(16))) float Ks[kTile * D];
+  __shared__ __attribute__((aligned(16))) float Vs[kTile * D];
   const int b = blockIdx.z, h = blockIdx.y;
   const int C = heads * D;
-  const int qi = blockIdx.x * kAttnBlock + threadIdx.x;
-  const bool live = qi < L;
+  const int q0 = blockIdx.x * blockDim.x * R + threadIdx.x;           // row r of this lane = q0 + r*blockDim
   const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
   const float* kp = qp + (long)C * L;
   const float* vp = kp + (long)C * L;
-  const long ooff = ((long)b * C + h * D) * L + qi;
-  float q[D], go[D], dq[D];
-  float delta = 0.f;
+  float q[R][D], acc[R][D], m[R], l[R];
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-    q[j] = live ? qp[(long)j * L + qi] * scale : 0.f;
-    go[j] = live ? d_o[ooff + (long)j * L] : 0.f;
-    delta += go[j] * (live ? o[ooff + (long)j * L] : 0.f);
-    dq[j] = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const int qi = q0 + r * blockDim.x;
+    m[r] = -INFINITY; l[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) { q[r][j] = qi < L ? qp[(long)j * L + qi] * scale : 0.f; acc[r][j] = 0.f; }
   }
-  const float ls = live ? lse[((long)b * heads + h) * L + qi] : 0.f;
   for (int k0 = 0; k0 < L; k0 += kTile) {
     __syncthreads();
-    for (int i = threadIdx.x; i < D * kTile; i += kAttnBlock) {
-      const int j = i / kTile, kk = i % kTile;
-      const bool in = k0 + kk < L;
-      Ks[j][kk] = in ? kp[(long)j * L + k0 + kk] : 0.f;
-      Vs[j][kk] = in ? vp[(long)j * L + k0 + kk] : 0.f;
-    }
+    stage_rows<D>(kp, Ks, k0, L, 1.f);
+    stage_rows<D>(vp, Vs, k0, L, 1.f);
     __syncthreads();
     const int nk = min(kTile, L - k0);
+    for (int c0 = 0; c0 < nk; c0 += kChunk) {
+      float s[R][kChunk], cm[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) cm[r] = m[r];
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        float kv[D];
+        RowVec<D>::load(Ks + (c0 + u) * D, kv);
+        const bool in = c0 + u < nk;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float a = 0.f;
+#pragma unroll
+          for (int j = 0; j < D; ++j) a += q[r][j] * kv[j];
+          s[r][u] = in ? a : -INFINITY;
+          cm[r] = fmaxf(cm[r], s[r][u]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float alpha = __expf(m[r] - cm[r]);      // m = -inf on the first chunk -> 0
+        l[r] *= alpha;
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc[r][j] *= alpha;
+        m[r] = cm[r];
+      }
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        float vv[D];
+        RowVec<D>::load(Vs + (c0 + u) * D, vv);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float p = __expf(s[r][u] - cm[r]);
+          l[r] += p;
+#pragma unroll
+          for (int j = 0; j < D; ++j) acc[r][j] += p * vv[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int qi = q0 + r * blockDim.x;
+    if (qi < L) {
+      const float inv = 1.0f / l[r];
+      float* op = o + ((long)b * C + h * D) * L + qi;
+#pragma unroll
+      for (int j = 0; j < D; ++j) op[(long)j * L] = acc[r][j] * inv;
+      lse[((long)b * heads + h) * L + qi] = m[r] + __logf(l[r]);
+    }
+  }
+}
+
+// dQ: lane = R query rows.  ds = p * (dp - delta) ; dq += ds * k * scale.  Also writes delta for the key pass.
+template <int D, int R>
+__global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                     const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                     float* __restrict__ dqkv, float* __restrict__ delta_out,
+                                                     int heads, int L, float scale) {
+  __shared__ __attribute__((aligned(16))) float Ks[kTile * D];
+  __shared__ __attribute__((aligned(16))) float Vs[kTile * D];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int C = heads * D;
+  const int q0 = blockIdx.x * blockDim.x * R + threadIdx.x;
+  const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
+  const float* kp = qp + (long)C * L;
+  const float* vp = kp + (long)C * L;
+  const long obase = ((long)b * C + h * D) * L;
+  float q[R][D], go[R][D], dq[R][D], delta[R], ls[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int qi = q0 + r * blockDim.x;
+    const bool live = qi < L;
+    delta[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      q[r][j] = live ? qp[(long)j * L + qi] * scale : 0.f;
+      go[r][j] = live ? d_o[obase + (long)j * L + qi] : 0.f;
+      delta[r] += go[r][j] * (live ? o[obase + (long)j * L + qi] : 0.f);
+      dq[r][j] = 0.f;
+    }
+    ls[r] = live ? lse[((long)b * heads + h) * L + qi] : 0.f;
+    if (live) delta_out[((long)b * heads + h) * L + qi] = delta[r];
+  }
+  for (int k0 = 0; k0 < L; k0 += kTile) {
+    __syncthreads();
+    stage_rows<D>(kp, Ks, k0, L, 1.f);
+    stage_rows<D>(vp, Vs, k0, L, 1.f);
+    __syncthreads();
+    const int nk = min(kTile, L - k0);
+#pragma unroll 2
     for (int u = 0; u < nk; ++u) {
-      float s = 0.f, dp = 0.f;
+      float kv[D], vv[D];
+      RowVec<D>::load(Ks + u * D, kv);
+      RowVec<D>::load(Vs + u * D, vv);
 #pragma unroll
-      for (int j = 0; j < D; ++j) { s += q[j] * Ks[j][u]; dp += go[j] * Vs[j][u]; }
-      const float ds = __expf(s - ls) * (dp - delta);
+      for (int r = 0; r < R; ++r) {
+        float sc = 0.f, dp = 0.f;
 #pragma unroll
-      for (int j = 0; j < D; ++j) dq[j] += ds * Ks[j][u];
+        for (int j = 0; j < D; ++j) { sc += q[r][j] * kv[j]; dp += go[r][j] * vv[j]; }
+        const float ds = __expf(sc - ls[r]) * (dp - delta[r]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) dq[r][j] += ds * kv[j];
+      }
     }
   }
-  if (live) {
-    float* dqp = dqkv + ((long)b * 3 * C + h * D) * L + qi;
 #pragma unroll
-    for (int j = 0; j < D; ++j) dqp[(long)j * L] = dq[j] * scale;
+  for (int r = 0; r < R; ++r) {
+    const int qi = q0 + r * blockDim.x;
+    if (qi < L) {
+      float* dqp = dqkv + ((long)b * 3 * C + h * D) * L + qi;
+#pragma unroll
+      for (int j = 0; j < D; ++j) dqp[(long)j * L] = dq[r][j] * scale;
+    }
   }
 }
 
-// dK, dV: lane = key.  Per query tile LDS holds Q*scale, dO, lse and delta.
-template <int D>
-__global__ __launch_bounds__(kAttnBlock) void attn_bwd_dkv_k(const float* __restrict__ qkv, const float* __restrict__ o,
-                                                             const float* __restrict__ d_o, const float* __restrict__ lse,
-                                                             float* __restrict__ dqkv, int heads, int L, float scale) {
-  __shared__ float Qs[D][kTile];
-  __shared__ float Gs[D][kTile];
+// dK, dV: lane = R key rows; LDS holds a tile of (scale*Q), dO, lse and delta rows.
+template <int D, int R>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                      const float* __restrict__ lse, const float* __restrict__ delta,
+                                                      float* __restrict__ dqkv, int heads, int L, float scale) {
+  __shared__ __attribute__((aligned(16))) float Qs[kTile * D];
+  __shared__ __attribute__((aligned(16))) float Gs[kTile * D];
   __shared__ float Ls[kTile];
   __shared__ float Ds[kTile];
   const int b = blockIdx.z, h = blockIdx.y;
   const int C = heads * D;
-  const int ki = blockIdx.x * kAttnBlock + threadIdx.x;
-  const bool live = ki < L;
+  const int kq0 = blockIdx.x * blockDim.x * R + threadIdx.x;
   const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
   const float* kp = qp + (long)C * L;
   const float* vp = kp + (long)C * L;
-  const float* op = o + ((long)b * C + h * D) * L;
   const float* gp = d_o + ((long)b * C + h * D) * L;
   const float* lp = lse + ((long)b * heads + h) * L;
-  float k[D], v[D], dk[D], dv[D];
+  const float* dlp = delta + ((long)b * heads + h) * L;
+  float k[R][D], v[R][D], dk[R][D], dv[R][D];
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-    k[j] = live ? kp[(long)j * L + ki] : 0.f;
-    v[j] = live ? vp[(long)j * L + ki] : 0.f;
-    dk[j] = 0.f; dv[j] = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const int ki = kq0 + r * blockDim.x;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      k[r][j] = ki < L ? kp[(long)j * L + ki] : 0.f;
+      v[r][j] = ki < L ? vp[(long)j * L + ki] : 0.f;
+      dk[r][j] = 0.f; dv[r][j] = 0.f;
+    }
   }
-  for (int q0 = 0; q0 < L; q0 += kTile) {
+  for (int t0 = 0; t0 < L; t0 += kTile) {
     __syncthreads();
-    for (int i = threadIdx.x; i < D * kTile; i += kAttnBlock) {
-      const int j = i / kTile, qq = i % kTile;
-      const bool in = q0 + qq < L;
-      Qs[j][qq] = in ? qp[(long)j * L + q0 + qq] * scale : 0.f;
-      Gs[j][qq] = in ? gp[(long)j * L + q0 + qq] : 0.f;
-    }
-    if (threadIdx.x < kTile) {
-      const int qq = threadIdx.x;
-      const bool in = q0 + qq < L;
-      float dl = 0.f;
-      if (in) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) dl += gp[(long)j * L + q0 + qq] * op[(long)j * L + q0 + qq];
-      }
-      Ds[qq] = dl;
-      Ls[qq] = in ? lp[q0 + qq] : INFINITY;          // exp(s - inf) = 0 for padded queries
+    stage_rows<D>(qp, Qs, t0, L, scale);
+    stage_rows<D>(gp, Gs, t0, L, 1.f);
+    for (int i = threadIdx.x; i < kTile; i += blockDim.x) {
+      const bool in = t0 + i < L;
+      Ls[i] = in ? lp[t0 + i] : INFINITY;              // exp(s - inf) = 0 for padded queries
+      Ds[i] = in ? dlp[t0 + i] : 0.f;
     }
     __syncthreads();
-    const int nq = min(kTile, L - q0);
+    const int nq = min(kTile, L - t0);
+#pragma unroll 2
     for (int u = 0; u < nq; ++u) {
-      float s = 0.f, dp = 0.f;
+      float qv[D], gv[D];
+      RowVec<D>::load(Qs + u * D, qv);
+      RowVec<D>::load(Gs + u * D, gv);
+      const float lsu = Ls[u], dlu = Ds[u];
 #pragma unroll
-      for (int j = 0; j < D; ++j) { s += Qs[j][u] * k[j]; dp += Gs[j][u] * v[j]; }
-      const float p = __expf(s - Ls[u]);
-      const float ds = p * (dp - Ds[u]);
+      for (int r = 0; r < R; ++r) {
+        float sc = 0.f, dp = 0.f;
 #pragma unroll
-      for (int j = 0; j < D; ++j) { dv[j] += p * Gs[j][u]; dk[j] += ds * Qs[j][u]; }   // Qs already carries `scale`
+        for (int j = 0; j < D; ++j) { sc += qv[j] * k[r][j]; dp += gv[j] * v[r][j]; }
+        const float p = __expf(sc - lsu);
+        const float ds = p * (dp - dlu);
+#pragma unroll
+        for (int j = 0; j < D; ++j) { dv[r][j] += p * gv[j]; dk[r][j] += ds * qv[j]; }   // qv already carries `scale`
+      }
     }
   }
-  if (live) {
-    float* dkp = dqkv + ((long)b * 3 * C + C + h * D) * L + ki;
-    float* dvp = dkp + (long)C * L;
 #pragma unroll
-    for (int j = 0; j < D; ++j) { dkp[(long)j * L] = dk[j]; dvp[(long)j * L] = dv[j]; }
+  for (int r = 0; r < R; ++r) {
+    const int ki = kq0 + r * blockDim.x;
+    if (ki < L) {
+      float* dkp = dqkv + ((long)b * 3 * C + C + h * D) * L + ki;
+      float* dvp = dkp + (long)C * L;
+#pragma unroll
+      for (int j = 0; j < D; ++j) { dkp[(long)j * L] = dk[r][j]; dvp[(long)j * L] = dv[r][j]; }
+    }
   }
 }
 
 }  // namespace afd
 using namespace afd;
 
-#define AFD_ATTN_DISPATCH(D_, KERNEL, ...)                                                     \
-  switch (D_) {                                                                                \
-    case 2:  hipLaunchKernelGGL(KERNEL<2>,  grid, dim3(kAttnBlock), 0, s, __VA_ARGS__); break; \
-    case 4:  hipLaunchKernelGGL(KERNEL<4>,  grid, dim3(kAttnBlock), 0, s, __VA_ARGS__); break; \
-    case 8:  hipLaunchKernelGGL(KERNEL<8>,  grid, dim3(kAttnBlock), 0, s, __VA_ARGS__); break; \
-    case 16: hipLaunchKernelGGL(KERNEL<16>, grid, dim3(kAttnBlock), 0, s, __VA_ARGS__); break; \
-    case 32: hipLaunchKernelGGL(KERNEL<32>, grid, dim3(kAttnBlock), 0, s, __VA_ARGS__); break; \
-    default: hipLaunchKernelGGL(KERNEL<64>, grid, dim3(kAttnBlock), 0, s, __VA_ARGS__); break; \
-  }
+// rows per lane by head dim (register budget) -- fwd/dq: 4,4,4,2,2,1 ; dkv (4 vectors per row): 4,4,2,2,1,1
+#define AFD_ATTN_CASE(D_, R_, KERNEL, ...)                                                          \
+  case D_: {                                                                                        \
+    const int rows = (L + (R_) - 1) / (R_);                                                         \
+    const dim3 block(rows <= 64 ? 64 : (rows <= 128 ? 128 : 256));                                  \
+    const dim3 grid((L + block.x * (R_) - 1) / (block.x * (R_)), heads, B);                         \
+    hipLaunchKernelGGL((KERNEL<D_, R_>), grid, block, 0, s, __VA_ARGS__);                           \
+  } break;
 
 extern "C" {
 
@@ -214,22 +276,41 @@ int afd_attn_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d
   AFD_REQUIRE(d == 2 || d == 4 || d == 8 || d == 16 || d == 32 || d == 64, "afd_attn_fwd: head dim %d not in {2,4,8,16,32,64}", d);
   AFD_REQUIRE(B <= 65535 && heads <= 65535, "afd_attn_fwd: grid too large");
   hipStream_t s = as_stream(st);
-  const dim3 grid((L + kAttnBlock - 1) / kAttnBlock, heads, B);
   const float scale = 1.0f / sqrtf((float)d);
-  AFD_ATTN_DISPATCH(d, attn_fwd_k, qkv, o, lse, heads, L, scale);
+  switch (d) {
+    AFD_ATTN_CASE(2, 4, attn_fwd_k, qkv, o, lse, heads, L, scale)
+    AFD_ATTN_CASE(4, 4, attn_fwd_k, qkv, o, lse, heads, L, scale)
+    AFD_ATTN_CASE(8, 4, attn_fwd_k, qkv, o, lse, heads, L, scale)
+    AFD_ATTN_CASE(16, 2, attn_fwd_k, qkv, o, lse, heads, L, scale)
+    AFD_ATTN_CASE(32, 2, attn_fwd_k, qkv, o, lse, heads, L, scale)
+    AFD_ATTN_CASE(64, 1, attn_fwd_k, qkv, o, lse, heads, L, scale)
+  }
   return check_launch("afd_attn_fwd");
 }
 
-int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
+int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta_ws,
                  int B, int heads, int d, int L, afd_stream_t st) {
-  AFD_REQUIRE(qkv && o && d_o && lse && dqkv && B > 0 && heads > 0 && L > 0, "afd_attn_bwd: bad argument");
+  AFD_REQUIRE(qkv && o && d_o && lse && dqkv && delta_ws && B > 0 && heads > 0 && L > 0, "afd_attn_bwd: bad argument");
   AFD_REQUIRE(d == 2 || d == 4 || d == 8 || d == 16 || d == 32 || d == 64, "afd_attn_bwd: head dim %d not in {2,4,8,16,32,64}", d);
   AFD_REQUIRE(B <= 65535 && heads <= 65535, "afd_attn_bwd: grid too large");
   hipStream_t s = as_stream(st);
-  const dim3 grid((L + kAttnBlock - 1) / kAttnBlock, heads, B);
   const float scale = 1.0f / sqrtf((float)d);
-  AFD_ATTN_DISPATCH(d, attn_bwd_dq_k, qkv, o, d_o, lse, dqkv, heads, L, scale);
-  AFD_ATTN_DISPATCH(d, attn_bwd_dkv_k, qkv, o, d_o, lse, dqkv, heads, L, scale);
+  switch (d) {
+    AFD_ATTN_CASE(2, 4, attn_bwd_dq_k, qkv, o, d_o, lse, dqkv, delta_ws, heads, L, scale)
+    AFD_ATTN_CASE(4, 4, attn_bwd_dq_k, qkv, o, d_o, lse, dqkv, delta_ws, heads, L, scale)
+    AFD_ATTN_CASE(8, 4, attn_bwd_dq_k, qkv, o, d_o, lse, dqkv, delta_ws, heads, L, scale)
+    AFD_ATTN_CASE(16, 2, attn_bwd_dq_k, qkv, o, d_o, lse, dqkv, delta_ws, heads, L, scale)
+    AFD_ATTN_CASE(32, 2, attn_bwd_dq_k, qkv, o, d_o, lse, dqkv, delta_ws, heads, L, scale)
+    AFD_ATTN_CASE(64, 1, attn_bwd_dq_k, qkv, o, d_o, lse, dqkv, delta_ws, heads, L, scale)
+  }
+  switch (d) {
+    AFD_ATTN_CASE(2, 4, attn_bwd_dkv_k, qkv, d_o, lse, delta_ws, dqkv, heads, L, scale)
+    AFD_ATTN_CASE(4, 4, attn_bwd_dkv_k, qkv, d_o, lse, delta_ws, dqkv, heads, L, scale)
+    AFD_ATTN_CASE(8, 2, attn_bwd_dkv_k, qkv, d_o, lse, delta_ws, dqkv, heads, L, scale)
+    AFD_ATTN_CASE(16, 2, attn_bwd_dkv_k, qkv, d_o, lse, delta_ws, dqkv, heads, L, scale)
+    AFD_ATTN_CASE(32, 1, attn_bwd_dkv_k, qkv, d_o, lse, delta_ws, dqkv, heads, L, scale)
+    AFD_ATTN_CASE(64, 1, attn_bwd_dkv_k, qkv, d_o, lse, delta_ws, dqkv, heads, L, scale)
+  }
   return check_launch("afd_attn_bwd");
 }
 

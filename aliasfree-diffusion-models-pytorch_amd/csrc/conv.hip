@@ -119,17 +119,31 @@ __global__ __launch_bounds__(256) void conv_direct_wgrad(const float* __restrict
   }
 }
 
-// dbias[n] = sum_{b,pix} dy[b,n,pix]; one workgroup per channel
-__global__ __launch_bounds__(256) void conv_dbias(const float* __restrict__ dy, float* __restrict__ db, int B, int Cout, long HW, int accumulate) {
-  __shared__ float red[16];
-  const int n = blockIdx.x;
+// dbias[n] = sum_{b,pix} dy[b,n,pix]: one wave per (b, n) plane writes part[b][n]; a second tiny kernel
+// sums the B partials per channel (fixed order: deterministic)
+__global__ __launch_bounds__(256) void conv_dbias_plane(const float* __restrict__ dy, float* __restrict__ part, long planes, int HW) {
+  const long pl = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (pl >= planes) return;
   float s = 0.f;
-  for (long p = threadIdx.x; p < (long)B * HW; p += blockDim.x) {
-    const long b = p / HW, pix = p % HW;
-    s += dy[(b * Cout + n) * HW + pix];
+  for (int i = lane; i < HW; i += 64) s += dy[pl * HW + i];
+  s = wave_sum(s);
+  if (lane == 0) part[pl] = s;
+}
+__global__ __launch_bounds__(256) void conv_dbias_final(const float* __restrict__ part, float* __restrict__ db, int B, int Cout, int accumulate) {
+  // 256 threads = 32 channels x 8 batch groups
+  __shared__ float red[8][33];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  float s = 0.f;
+  if (c < Cout) for (int b = g; b < B; b += 8) s += part[(long)b * Cout + c];
+  red[g][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (g == 0 && c < Cout) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+    db[c] = accumulate ? db[c] + t : t;
   }
-  s = block_sum(s, red);
-  if (threadIdx.x == 0) db[n] = accumulate ? db[n] + s : s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -291,6 +305,106 @@ __global__ __launch_bounds__(256) void conv_mfma(const float* __restrict__ x, co
 }
 
 // ------------------------------------------------------------------------------------------
+// forward / dgrad for SMALL pixel counts (4x4 / 8x8 layers): 32 channels x 64 pixels per workgroup
+// (4-8x more workgroups than the 64x128 tile), the four waves split every 32-channel K chunk four
+// ways (8 channels each) and their accumulators meet in LDS at the end (in-workgroup split-K: no
+// global partials, deterministic order).
+// ------------------------------------------------------------------------------------------
+template <int T, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_mfma_sk(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, const float* __restrict__ res,
+                                                    float* __restrict__ y, int B, int K, int N, int H, int W, int act,
+                                                    TileGeom g) {
+  constexpr int PT = 64, BN = 32, KC = 32, KW = KC / 4, TM = 2, HALO = (T == 9) ? 1 : 0;
+  constexpr int WS = KC * T + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                                  // [BN][WS]
+  float* Xs = smem + BN * WS;                        // [KC][g.XS]
+  const int HW = H * W;
+  const long P = (long)B * HW;
+  const long p0 = (long)blockIdx.y * PT;
+  const int n0 = blockIdx.x * BN;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  int spos = threadIdx.x, soff = -1; long simg = 0;   // g.XS <= 256 on this path: one position per thread
+  if (spos < g.XS) pos_source(spos, p0, H, W, P, g, HALO, simg, soff);
+  int poff[TM];
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt) poff[mt] = pix_lds_off(mt * 32 + l31, W, g, HALO);
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    __syncthreads();
+    if (!DGRAD) {
+      for (int i = threadIdx.x; i < BN * KC * T; i += 256) {
+        const int n = i / (KC * T), r = i % (KC * T);
+        const bool ok = (n0 + n < N) && (k0 + r / T < K);
+        Ws[n * WS + r] = ok ? w[((long)(n0 + n) * K + k0) * T + r] : 0.f;
+      }
+    } else {
+      for (int i = threadIdx.x; i < KC * BN * T; i += 256) {
+        const int kc = i / (BN * T), r = i % (BN * T);
+        const int n = r / T, t = r % T;
+        const bool ok = (n0 + n < N) && (k0 + kc < K);
+        Ws[n * WS + kc * T + t] = ok ? w[((long)(k0 + kc) * N + n0) * T + r] : 0.f;
+      }
+    }
+    if (spos < g.XS) {
+#pragma unroll 8
+      for (int kc = 0; kc < KC; ++kc) {
+        float v = 0.f;
+        if (soff >= 0 && k0 + kc < K) v = x[(simg * K + k0 + kc) * (long)HW + soff];
+        Xs[kc * g.XS + spos] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int toff = (T == 9) ? ((t / 3 - 1) * g.Wp + (t % 3 - 1)) : 0;
+      const int tw = DGRAD ? (T - 1 - t) : t;
+#pragma unroll
+      for (int k2 = 0; k2 < KW / 2; ++k2) {
+        const int kc = wv * KW + 2 * k2 + half;
+        const float a = Ws[l31 * WS + kc * T + tw];
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Xs[kc * g.XS + poff[mt] + toff], acc[mt], 0, 0, 0);
+      }
+    }
+  }
+  // ---- cross-wave reduction through LDS, then the epilogue (each thread owns 8 outputs)
+  __syncthreads();
+  float* red = smem;                                  // [4 waves][TM][16][64]
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wv * TM + mt) * 16 + r) * 64 + lane] = acc[mt][r];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < (TM * 16 * 64) / 256; ++e) {
+    const int idx = threadIdx.x + 256 * e;
+    const int mt = idx / 1024, r = (idx / 64) % 16, ln = idx % 64;
+    float v = (red[idx] + red[idx + 2048]) + (red[idx + 4096] + red[idx + 6144]);
+    const long p = p0 + mt * 32 + (ln & 31);
+    const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+    if (p < P && n < N) {
+      const long b = p / HW; const int pix = p % HW;
+      const long o = (b * N + n) * (long)HW + pix;
+      if (bias) v += bias[n];
+      if (act == 1) v = gelu_erf(v);
+      if (res) v += res[o];
+      y[o] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // wgrad: part[split][cout][cin][tap] = sum_{pixels of the split} dY[cout][p] * X[cin][p + tap]
 // ------------------------------------------------------------------------------------------
 template <int T>
@@ -395,10 +509,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
   }
 }
 
-__global__ void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, long n, int splits, int accumulate) {
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, long n, int splits, int accumulate) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(long)k * n + i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // 4 independent chains: the loads overlap
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+      s0 += part[(long)k * n + i]; s1 += part[(long)(k + 1) * n + i];
+      s2 += part[(long)(k + 2) * n + i]; s3 += part[(long)(k + 3) * n + i];
+    }
+    for (; k < splits; ++k) s0 += part[(long)k * n + i];
+    const float s = (s0 + s1) + (s2 + s3);
     dw[i] = accumulate ? dw[i] + s : s;
   }
 }
@@ -408,14 +528,30 @@ __global__ void wgrad_reduce(const float* __restrict__ part, float* __restrict__
 // ------------------------------------------------------------------------------------------
 static inline bool use_mfma(int K, int N, int H, int W, int PT) { return K >= 8 && N >= 8 && tile_ok(H, W, PT); }
 
+static int g_conv_path = 0;       // 0 auto, 1 force the 64x128 tile, 2 force the split-K small tile (tests)
+
 template <int T, bool DGRAD>
 static int launch_mfma(const float* x, const float* w, const float* bias, const float* res, float* y,
                        int B, int K, int N, int H, int W, int act, hipStream_t s) {
   constexpr int KC = (T == 9) ? 8 : 32;
-  const TileGeom g = make_geom(H, W, 128, T == 9 ? 1 : 0);
-  if (g.XS > 512) return -1;                                            // staging plan holds 2 positions per thread
   const long P = (long)B * H * W;
   const unsigned ptiles = (unsigned)((P + 127) / 128);
+  // few workgroups under the big tile -> small tile with in-workgroup split-K
+  const long wgs_big = (long)ptiles * ((N + 63) / 64);
+  const bool want_sk = g_conv_path == 2 || (g_conv_path == 0 && wgs_big < 384);
+  if (T == 9 && want_sk && K >= 32 && tile_ok(H, W, 64)) {
+    const TileGeom g = make_geom(H, W, 64, 1);
+    if (g.XS <= 256) {
+      const size_t lds_main = sizeof(float) * (32 * (32 * T + 1) + (size_t)32 * g.XS);
+      const size_t lds_red = sizeof(float) * 4 * 2 * 16 * 64;
+      const size_t lds = lds_main > lds_red ? lds_main : lds_red;
+      hipLaunchKernelGGL((conv_mfma_sk<T, DGRAD>), dim3((N + 31) / 32, (unsigned)((P + 63) / 64)), dim3(256), lds, s,
+                         x, w, bias, res, y, B, K, N, H, W, act, g);
+      return 0;
+    }
+  }
+  const TileGeom g = make_geom(H, W, 128, T == 9 ? 1 : 0);
+  if (g.XS > 512) return -1;                                            // staging plan holds 2 positions per thread
   if (N > 32) {
     const size_t lds = sizeof(float) * (64 * (KC * T + 1) + (size_t)KC * g.XS);
     hipLaunchKernelGGL((conv_mfma<T, DGRAD, 64, KC>), dim3((N + 63) / 64, ptiles), dim3(256), lds, s, x, w, bias, res, y, B, K, N, H, W, act, g);
@@ -429,7 +565,7 @@ static int launch_mfma(const float* x, const float* w, const float* bias, const 
 static inline int wgrad_splits(int B, int Cin, int Cout, int H, int W) {
   const long nchunks = ((long)B * H * W + 63) / 64;
   const long tiles = (long)((Cout + 63) / 64) * ((Cin + 63) / 64);
-  long s = 1024 / tiles;
+  long s = 512 / tiles;                 // ~2 workgroups per CU is enough; more splits only add partial-slab traffic
   if (s < 1) s = 1;
   if (s > nchunks) s = nchunks;
   return (int)s;
@@ -439,6 +575,12 @@ static inline int wgrad_splits(int B, int Cin, int Cout, int H, int W) {
 using namespace afd;
 
 extern "C" {
+
+int afd_debug_conv_path(int mode) {
+  AFD_REQUIRE(mode >= 0 && mode <= 2, "afd_debug_conv_path: mode must be 0 (auto), 1 (big tile) or 2 (split-K tile)");
+  g_conv_path = mode;
+  return AFD_OK;
+}
 
 int afd_conv_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
                  int B, int Cin, int Cout, int H, int W, int ksize, int act, afd_stream_t st) {
@@ -476,8 +618,8 @@ int afd_conv_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, i
 
 size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ksize) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
-  if (!tile_ok(H, W, 64)) return 0;
-  return sizeof(float) * (size_t)wgrad_splits(B, Cin, Cout, H, W) * Cout * Cin * ksize * ksize;
+  if (!tile_ok(H, W, 64)) return sizeof(float) * (size_t)B * Cout;
+  return sizeof(float) * ((size_t)wgrad_splits(B, Cin, Cout, H, W) * Cout * Cin * ksize * ksize + (size_t)B * Cout);
 }
 
 int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
@@ -504,7 +646,15 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
     if (ksize == 3) hipLaunchKernelGGL(conv_direct_wgrad<3>, grid, dim3(256), 0, s, x, dy, dw, B, Cin, Cout, H, W, accumulate);
     else hipLaunchKernelGGL(conv_direct_wgrad<1>, grid, dim3(256), 0, s, x, dy, dw, B, Cin, Cout, H, W, accumulate);
   }
-  if (dbias) hipLaunchKernelGGL(conv_dbias, dim3(Cout), dim3(256), 0, s, dy, dbias, B, Cout, (long)H * W, accumulate);
+  if (dbias) {
+    AFD_REQUIRE(workspace, "afd_conv_wgrad: workspace is NULL");
+    // the (B, Cout) plane partials live at the END of the workspace (after the split-K slabs)
+    const size_t wsz = afd_conv_wgrad_workspace_bytes(B, Cin, Cout, H, W, ksize) / sizeof(float);
+    float* bp = static_cast<float*>(workspace) + (wsz - (size_t)B * Cout);
+    const long planes = (long)B * Cout;
+    hipLaunchKernelGGL(conv_dbias_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, dy, bp, planes, H * W);
+    hipLaunchKernelGGL(conv_dbias_final, dim3((Cout + 31) / 32), dim3(256), 0, s, bp, dbias, B, Cout, accumulate);
+  }
   return check_launch("afd_conv_wgrad");
 }
 

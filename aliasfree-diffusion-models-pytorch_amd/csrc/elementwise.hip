@@ -121,13 +121,24 @@ __global__ void copy_batched_k(const float* __restrict__ s, float* __restrict__ 
 __global__ void add_k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n) {
   AFD_GRID_STRIDE(i, n) y[i] = a[i] + b[i];
 }
-// out[j] = sum_i in[i*cols + j]; one thread per column, fixed order (deterministic)
-__global__ void colsum_k(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int accumulate) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= cols) return;
-  float s = 0.f;
-  for (int i = 0; i < rows; ++i) s += in[(long)i * cols + j];
-  out[j] = accumulate ? out[j] + s : s;
+// out[j] = sum_i in[i*cols + j].  256 threads = 32 columns x 8 row groups; fixed order (deterministic)
+__global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int accumulate) {
+  __shared__ float red[8][33];
+  const int j = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  float s0 = 0.f, s1 = 0.f;
+  if (j < cols) {
+    int i = g;
+    for (; i + 8 < rows; i += 16) { s0 += in[(long)i * cols + j]; s1 += in[(long)(i + 8) * cols + j]; }
+    if (i < rows) s0 += in[(long)i * cols + j];
+  }
+  red[g][threadIdx.x & 31] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && j < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+    out[j] = accumulate ? out[j] + t : t;
+  }
 }
 
 // ---- time embedding ------------------------------------------------------------------------
@@ -161,15 +172,29 @@ __global__ void silu_linear_dw_k(const float* __restrict__ temb, const float* __
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)N * K) return;
   const int n = i / K, k = i % K;
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) s += dout[(long)b * N + n] * silu(temb[(long)b * K + k]);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 4 <= B; b += 4) {
+    s0 += dout[(long)b * N + n] * silu(temb[(long)b * K + k]);
+    s1 += dout[(long)(b + 1) * N + n] * silu(temb[(long)(b + 1) * K + k]);
+    s2 += dout[(long)(b + 2) * N + n] * silu(temb[(long)(b + 2) * K + k]);
+    s3 += dout[(long)(b + 3) * N + n] * silu(temb[(long)(b + 3) * K + k]);
+  }
+  for (; b < B; ++b) s0 += dout[(long)b * N + n] * silu(temb[(long)b * K + k]);
+  const float s = (s0 + s1) + (s2 + s3);
   dw[i] = accumulate ? dw[i] + s : s;
 }
 __global__ void silu_linear_db_k(const float* __restrict__ dout, float* __restrict__ db, int B, int N, int accumulate) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) s += dout[(long)b * N + n];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 4 <= B; b += 4) {
+    s0 += dout[(long)b * N + n]; s1 += dout[(long)(b + 1) * N + n];
+    s2 += dout[(long)(b + 2) * N + n]; s3 += dout[(long)(b + 3) * N + n];
+  }
+  for (; b < B; ++b) s0 += dout[(long)b * N + n];
+  const float s = (s0 + s1) + (s2 + s3);
   db[n] = accumulate ? db[n] + s : s;
 }
 // dtemb[b,k] += silu'(temb[b,k]) * sum_n dout[b,n] w[n,k]
@@ -243,7 +268,7 @@ int afd_add(const float* a, const float* b, float* y, long n, afd_stream_t st) {
 }
 int afd_colsum(const float* in, float* out, int rows, int cols, int accumulate, afd_stream_t st) {
   AFD_REQUIRE(in && out && rows > 0 && cols > 0, "afd_colsum: bad argument");
-  hipLaunchKernelGGL(colsum_k, dim3((cols + 255) / 256), dim3(256), 0, as_stream(st), in, out, rows, cols, accumulate);
+  hipLaunchKernelGGL(colsum_k, dim3((cols + 31) / 32), dim3(256), 0, as_stream(st), in, out, rows, cols, accumulate);
   return check_launch("afd_colsum");
 }
 int afd_pos_encoding(const int64_t* t, const float* inv_freq, float* temb, int B, int half, afd_stream_t st) {

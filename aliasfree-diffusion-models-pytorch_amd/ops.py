@@ -316,7 +316,8 @@ class Attention(torch.autograd.Function):
         C, L = C3 // 3, H * W
         do = _c(do)
         dqkv = torch.empty_like(qkv)
-        lib().afd_attn_bwd(_p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), B, ctx.heads, C // ctx.heads, L, _stream())
+        delta = torch.empty_like(lse)
+        lib().afd_attn_bwd(_p(qkv), _p(o), _p(do), _p(lse), _p(dqkv), _p(delta), B, ctx.heads, C // ctx.heads, L, _stream())
         return dqkv, None
 
 

@@ -118,9 +118,9 @@ def kernel_table(dev, B):
     for (C, S) in ATTN:
         Lq = S * S
         qkv = torch.randn(B, 3 * C, S, S, device=dev); o = torch.empty(B, C, S, S, device=dev)
-        lse = torch.empty(B, 4, Lq, device=dev); dq = torch.empty_like(qkv)
+        lse = torch.empty(B, 4, Lq, device=dev); dq = torch.empty_like(qkv); dl = torch.empty_like(lse)
         tf = ev_time(lambda: L.afd_attn_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, 4, C // 4, Lq, s), reps=3, warm=1)
-        tb = ev_time(lambda: L.afd_attn_bwd(qkv.data_ptr(), o.data_ptr(), o.data_ptr(), lse.data_ptr(), dq.data_ptr(), B, 4, C // 4, Lq, s), reps=3, warm=1)
+        tb = ev_time(lambda: L.afd_attn_bwd(qkv.data_ptr(), o.data_ptr(), o.data_ptr(), lse.data_ptr(), dq.data_ptr(), dl.data_ptr(), B, 4, C // 4, Lq, s), reps=3, warm=1)
         fl = 4.0 * B * Lq * Lq * C
         add("attn_fwd", tf, fl)
         add("attn_bwd", tb, 2.5 * fl, launches=2)

@@ -97,7 +97,11 @@ int afd_colsum(const float* in, float* out, int rows, int cols, int accumulate, 
  * x (B,Cin,H,W), w (Cout,Cin,k,k) k in {1,3}, y (B,Cout,H,W).
  * epilogue: y = act(conv + bias[co]) + res      (bias/res may be NULL; act 0 none, 1 exact GELU)
  * dgrad:   dx = conv_transpose(dy, w)           wgrad: dw = sum_b,hw dy (x) x ; dbias = sum dy
- * wgrad needs a workspace (split-K partials); size from afd_conv_wgrad_workspace_bytes. */
+ * wgrad needs a workspace (split-K partial slabs + the (B,Cout) dbias partials); size from
+ * afd_conv_wgrad_workspace_bytes. */
+/* test hook: 0 = choose the tile by workgroup count (default), 1 = always the 64x128 tile,
+ * 2 = always the 32x64 in-workgroup split-K tile (when the shape allows it) */
+int afd_debug_conv_path(int mode);
 int afd_conv_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
                  int B, int Cin, int Cout, int H, int W, int ksize, int act, afd_stream_t stream);
 int afd_conv_dgrad(const float* dy, const float* w, float* dx,
@@ -121,7 +125,7 @@ int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int
  * o (B,C,L); lse (B,heads,L) saved for backward.  Never materialises the L x L scores. */
 int afd_attn_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d, int L, afd_stream_t stream);
 int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
-                 int B, int heads, int d, int L, afd_stream_t stream);
+                 float* delta_workspace /* (B,heads,L) floats */, int B, int heads, int d, int L, afd_stream_t stream);
 
 /* ---- elementwise / pooling used by variants 0 and 2 --------------------------------------------
  * gelu: nn.GELU (ddpm_utils.py:64); maxpool: nn.MaxPool2d(2) (:203,258);

@@ -198,9 +198,18 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("path", ["auto", "big", "splitk"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[5]}" for c in CONV_CASES])
-def test_conv_fwd_dgrad_wgrad(A, case):
-    _, ops, dev = A
+def test_conv_fwd_dgrad_wgrad(A, case, path):
+    afdm, ops, dev = A
+    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2}[path])
+    try:
+        _conv_case(ops, dev, case)
+    finally:
+        afdm.lib().afd_debug_conv_path(0)
+
+
+def _conv_case(ops, dev, case):
     B, Cin, Cout, H, W, ks, has_bias, has_res = case
     g = _g(B * 1000 + Cin + Cout + H)
     x = torch.randn(B, Cin, H, W, generator=g)
