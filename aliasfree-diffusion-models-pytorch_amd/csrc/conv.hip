@@ -200,6 +200,68 @@ __device__ __forceinline__ void pos_source(int pos, long p0, int H, int W, long 
 //   FWD:   k = cin,  n = cout, w index ((n*K + k)*T + t)
 //   DGRAD: k = cout, n = cin,  w index ((k*N + n)*T + (T-1-t))   (taps flipped)
 // ------------------------------------------------------------------------------------------
+// Register staging shared by conv_mfma / conv_mfma_sk: every thread owns NW weight elements and up
+// to NP x KC activation elements of a K chunk.  `fetch` issues ALL their global loads back to back
+// (clamped addresses, no branches); `commit` writes them to LDS with the out-of-range ones zeroed.
+// The main loop fetches chunk k+1 before the MFMAs of chunk k, so the load latency hides behind
+// the matrix work even with a single resident workgroup (async-stage split).
+template <int T, bool DGRAD, int BN, int KC, int NP>
+struct Stager {
+  static constexpr int WS = KC * T + 1;
+  static constexpr int NW = BN * KC * T / 256;
+  static_assert(BN * KC * T % 256 == 0, "weight chunk must divide over 256 threads");
+  float wreg[NW];
+  float xreg[NP][KC];
+  unsigned long long wok;       // bit e: weight element e is inside the tensor
+  unsigned xok[NP];             // bit kc: channel k0+kc < K (and the position is not halo)
+
+  __device__ __forceinline__ void fetch(const float* __restrict__ w, const float* __restrict__ x, int k0, int K, int N,
+                                        int n0, int HW, const int (&spos)[NP], const int (&soff)[NP],
+                                        const long (&simg)[NP], int XS) {
+    wok = 0;
+#pragma unroll
+    for (int e = 0; e < NW; ++e) {
+      const int i = threadIdx.x + 256 * e;
+      int n, kc, t;
+      if (!DGRAD) { n = i / (KC * T); const int r = i % (KC * T); kc = r / T; t = r % T; }
+      else        { kc = i / (BN * T); const int r = i % (BN * T); n = r / T; t = r % T; }
+      const bool ok = (n0 + n < N) && (k0 + kc < K);
+      const int nc = min(n0 + n, N - 1), kk = min(k0 + kc, K - 1);
+      wreg[e] = DGRAD ? w[(unsigned)((kk * N + nc) * T + t)] : w[(unsigned)((nc * K + kk) * T + t)];   // 32-bit offsets (host checks sizes)
+      wok |= (ok ? 1ull : 0ull) << e;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      xok[p] = 0;
+      if (spos[p] < XS) {
+        const unsigned xb = soff[p] >= 0 ? (unsigned)simg[p] * (unsigned)(K * HW) + (unsigned)soff[p] : 0u;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          xreg[p][kc] = x[xb + (unsigned)(min(k0 + kc, K - 1) * HW)];
+          xok[p] |= ((soff[p] >= 0 && k0 + kc < K) ? 1u : 0u) << kc;
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void commit(float* __restrict__ Ws, float* __restrict__ Xs, const int (&spos)[NP], int XS) const {
+#pragma unroll
+    for (int e = 0; e < NW; ++e) {
+      const int i = threadIdx.x + 256 * e;
+      int dst;
+      if (!DGRAD) { dst = (i / (KC * T)) * WS + i % (KC * T); }
+      else        { const int kc = i / (BN * T), r = i % (BN * T); dst = (r / T) * WS + kc * T + r % T; }
+      Ws[dst] = ((wok >> e) & 1ull) ? wreg[e] : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      if (spos[p] < XS) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) Xs[kc * XS + spos[p]] = ((xok[p] >> kc) & 1u) ? xreg[p][kc] : 0.f;
+      }
+  }
+};
+
 template <int T, bool DGRAD, int BN, int KC>
 __global__ __launch_bounds__(256) void conv_mfma(const float* __restrict__ x, const float* __restrict__ w,
                                                  const float* __restrict__ bias, const float* __restrict__ res,
@@ -208,6 +270,7 @@ __global__ __launch_bounds__(256) void conv_mfma(const float* __restrict__ x, co
   constexpr int PT = 128, HALO = (T == 9) ? 1 : 0;
   constexpr int TM = (BN == 64) ? 2 : 1;            // 32-pixel MFMA tiles per wave
   constexpr int WS = KC * T + 1;                    // odd row stride of the weight image
+  constexpr int NP = (T == 9) ? 2 : 1;              // LDS positions per thread (XS <= 512 / <= 256)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ws = smem;                                  // [BN][WS]
   float* Xs = smem + BN * WS;                        // [KC][g.XS]
@@ -220,10 +283,10 @@ __global__ __launch_bounds__(256) void conv_mfma(const float* __restrict__ x, co
   const int mw = (BN == 64) ? (wv & 1) * 64 : wv * 32;                  // wave's first pixel in the tile
   const int half = lane >> 5, l31 = lane & 31;
 
-  // chunk-invariant staging plan for X: up to 2 positions per thread
-  int spos[2], soff[2]; long simg[2];
+  // chunk-invariant staging plan for X
+  int spos[NP], soff[NP]; long simg[NP];
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
+  for (int e = 0; e < NP; ++e) {
     spos[e] = threadIdx.x + 256 * e;
     soff[e] = -1; simg[e] = 0;
     if (spos[e] < g.XS) pos_source(spos[e], p0, H, W, P, g, HALO, simg[e], soff[e]);
@@ -238,36 +301,13 @@ __global__ __launch_bounds__(256) void conv_mfma(const float* __restrict__ x, co
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
+  Stager<T, DGRAD, BN, KC, NP> st;
+  st.fetch(w, x, 0, K, N, n0, HW, spos, soff, simg, g.XS);
   for (int k0 = 0; k0 < K; k0 += KC) {
+    __syncthreads();                                  // previous chunk's fragment reads are done
+    st.commit(Ws, Xs, spos, g.XS);
     __syncthreads();
-    // ---- stage weights
-    if (!DGRAD) {
-      for (int i = threadIdx.x; i < BN * KC * T; i += 256) {
-        const int n = i / (KC * T), r = i % (KC * T);
-        const bool ok = (n0 + n < N) && (k0 + r / T < K);
-        Ws[n * WS + r] = ok ? w[((long)(n0 + n) * K + k0) * T + r] : 0.f;
-      }
-    } else {
-      for (int i = threadIdx.x; i < KC * BN * T; i += 256) {
-        const int kc = i / (BN * T), r = i % (BN * T);
-        const int n = r / T, t = r % T;
-        const bool ok = (n0 + n < N) && (k0 + kc < K);
-        Ws[n * WS + kc * T + t] = ok ? w[((long)(k0 + kc) * N + n0) * T + r] : 0.f;
-      }
-    }
-    // ---- stage activations (zero halo, zero beyond K / batch)
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      if (spos[e] < g.XS) {
-        for (int kc = 0; kc < KC; ++kc) {
-          float v = 0.f;
-          if (soff[e] >= 0 && k0 + kc < K) v = x[(simg[e] * K + k0 + kc) * (long)HW + soff[e]];
-          Xs[kc * g.XS + spos[e]] = v;
-        }
-      }
-    }
-    __syncthreads();
-    // ---- MFMA
+    if (k0 + KC < K) st.fetch(w, x, k0 + KC, K, N, n0, HW, spos, soff, simg, g.XS);   // in flight during the MFMAs
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int toff = (T == 9) ? ((t / 3 - 1) * g.Wp + (t % 3 - 1)) : 0;
@@ -327,8 +367,8 @@ __global__ __launch_bounds__(256) void conv_mfma_sk(const float* __restrict__ x,
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
 
-  int spos = threadIdx.x, soff = -1; long simg = 0;   // g.XS <= 256 on this path: one position per thread
-  if (spos < g.XS) pos_source(spos, p0, H, W, P, g, HALO, simg, soff);
+  int spos[1] = {(int)threadIdx.x}, soff[1] = {-1}; long simg[1] = {0};   // g.XS <= 256 on this path
+  if (spos[0] < g.XS) pos_source(spos[0], p0, H, W, P, g, HALO, simg[0], soff[0]);
   int poff[TM];
 #pragma unroll
   for (int mt = 0; mt < TM; ++mt) poff[mt] = pix_lds_off(mt * 32 + l31, W, g, HALO);
@@ -339,31 +379,13 @@ __global__ __launch_bounds__(256) void conv_mfma_sk(const float* __restrict__ x,
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
+  Stager<T, DGRAD, BN, KC, 1> st;
+  st.fetch(w, x, 0, K, N, n0, HW, spos, soff, simg, g.XS);
   for (int k0 = 0; k0 < K; k0 += KC) {
     __syncthreads();
-    if (!DGRAD) {
-      for (int i = threadIdx.x; i < BN * KC * T; i += 256) {
-        const int n = i / (KC * T), r = i % (KC * T);
-        const bool ok = (n0 + n < N) && (k0 + r / T < K);
-        Ws[n * WS + r] = ok ? w[((long)(n0 + n) * K + k0) * T + r] : 0.f;
-      }
-    } else {
-      for (int i = threadIdx.x; i < KC * BN * T; i += 256) {
-        const int kc = i / (BN * T), r = i % (BN * T);
-        const int n = r / T, t = r % T;
-        const bool ok = (n0 + n < N) && (k0 + kc < K);
-        Ws[n * WS + kc * T + t] = ok ? w[((long)(k0 + kc) * N + n0) * T + r] : 0.f;
-      }
-    }
-    if (spos < g.XS) {
-#pragma unroll 8
-      for (int kc = 0; kc < KC; ++kc) {
-        float v = 0.f;
-        if (soff >= 0 && k0 + kc < K) v = x[(simg * K + k0 + kc) * (long)HW + soff];
-        Xs[kc * g.XS + spos] = v;
-      }
-    }
+    st.commit(Ws, Xs, spos, g.XS);
     __syncthreads();
+    if (k0 + KC < K) st.fetch(w, x, k0 + KC, K, N, n0, HW, spos, soff, simg, g.XS);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int toff = (T == 9) ? ((t / 3 - 1) * g.Wp + (t % 3 - 1)) : 0;
@@ -452,21 +474,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
       const long b = pc / HW + gdb;
       const int pix = (HW >= PT) ? (int)(pc % HW) + gpix : gpix;
       const bool pin = (pc + pp) < P;
+      const long gb = pin ? b * Cout * (long)HW + pix : 0;
+      float gv_[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) gv_[e] = dy[gb + (long)min(n0 + (int)(threadIdx.x >> 6) + 4 * e, Cout - 1) * HW];
+#pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = (threadIdx.x >> 6) + 4 * e;
-        float v = 0.f;
-        if (pin && n0 + n < Cout) v = dy[(b * Cout + n0 + n) * (long)HW + pix];
-        Gs[n * S1 + pp] = v;
+        Gs[n * S1 + pp] = (pin && n0 + n < Cout) ? gv_[e] : 0.f;
       }
     }
     if (npos <= 256) {
       if (xact) {
         long img; int off;
         pos_source(xpos, pc, H, W, P, g, HALO, img, off);
-        for (int j = xgrp; j < 64; j += ngrp) {
-          float v = 0.f;
-          if (off >= 0 && c0 + j < Cin) v = x[(img * Cin + c0 + j) * (long)HW + off];
-          Xs[j * XSP + xpos] = v;
+        const long xb = off >= 0 ? img * Cin * (long)HW + off : 0;
+        for (int j0 = xgrp; j0 < 64; j0 += 8 * ngrp) {
+          float xv_[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) xv_[u] = x[xb + (long)min(c0 + j0 + u * ngrp, Cin - 1) * HW];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * ngrp;
+            if (j < 64) Xs[j * XSP + xpos] = (off >= 0 && c0 + j < Cin) ? xv_[u] : 0.f;
+          }
         }
       }
     } else {
@@ -535,10 +566,15 @@ static int launch_mfma(const float* x, const float* w, const float* bias, const 
                        int B, int K, int N, int H, int W, int act, hipStream_t s) {
   constexpr int KC = (T == 9) ? 8 : 32;
   const long P = (long)B * H * W;
+  if (P * K >= (1L << 31) || (long)K * N * T >= (1L << 31)) return -1;   // staging uses 32-bit element offsets
   const unsigned ptiles = (unsigned)((P + 127) / 128);
-  // few workgroups under the big tile -> small tile with in-workgroup split-K
-  const long wgs_big = (long)ptiles * ((N + 63) / 64);
-  const bool want_sk = g_conv_path == 2 || (g_conv_path == 0 && wgs_big < 384);
+  // tile choice by workgroup count (measured, tools/conv_paths.py): the 64x128 tile wins once it gives
+  // every CU a workgroup; below that the 32x128 tile (twice the workgroups), and for the smallest
+  // layers the 32x64 tile with in-workgroup split-K
+  const long wgs64 = (long)ptiles * ((N + 63) / 64), wgs32 = (long)ptiles * ((N + 31) / 32);
+  bool use32 = N <= 32 || (wgs64 < 256 && wgs32 >= 256);
+  const bool want_sk = g_conv_path == 2 || (g_conv_path == 0 && wgs64 < 256 && wgs32 < 256);
+  if (g_conv_path == 1) use32 = N <= 32;
   if (T == 9 && want_sk && K >= 32 && tile_ok(H, W, 64)) {
     const TileGeom g = make_geom(H, W, 64, 1);
     if (g.XS <= 256) {
@@ -552,7 +588,7 @@ static int launch_mfma(const float* x, const float* w, const float* bias, const 
   }
   const TileGeom g = make_geom(H, W, 128, T == 9 ? 1 : 0);
   if (g.XS > 512) return -1;                                            // staging plan holds 2 positions per thread
-  if (N > 32) {
+  if (!use32) {
     const size_t lds = sizeof(float) * (64 * (KC * T + 1) + (size_t)KC * g.XS);
     hipLaunchKernelGGL((conv_mfma<T, DGRAD, 64, KC>), dim3((N + 63) / 64, ptiles), dim3(256), lds, s, x, w, bias, res, y, B, K, N, H, W, act, g);
   } else {
