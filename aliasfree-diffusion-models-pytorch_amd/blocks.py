@@ -44,15 +44,16 @@ class SelfAttention(nn.Module):
         x = x.reshape(-1, C, self.size, self.size)
         as1x1 = lambda w: w.reshape(w.shape[0], w.shape[1], 1, 1)
         h = ops.LayerNormC.apply(x, self.ln.weight, self.ln.bias)
-        qkv = ops.conv(h, as1x1(self.mha.in_proj_weight), self.mha.in_proj_bias)
+        lin = lambda z, w, b, res=None: ops.conv(z, as1x1(w), b, res=res, w_param=w, b_param=b)
+        qkv = lin(h, self.mha.in_proj_weight, self.mha.in_proj_bias)
         att = ops.Attention.apply(qkv, self.heads)
-        a = ops.conv(att, as1x1(self.mha.out_proj.weight), self.mha.out_proj.bias, res=x)
+        a = lin(att, self.mha.out_proj.weight, self.mha.out_proj.bias, x)
         f = ops.LayerNormC.apply(a, self.ff_self[0].weight, self.ff_self[0].bias)
         if torch.is_grad_enabled():
-            f = ops.Gelu.apply(ops.conv(f, as1x1(self.ff_self[1].weight), self.ff_self[1].bias))
+            f = ops.Gelu.apply(lin(f, self.ff_self[1].weight, self.ff_self[1].bias))
         else:
             f = ops.conv_infer(f, as1x1(self.ff_self[1].weight), self.ff_self[1].bias, act=1)
-        return ops.conv(f, as1x1(self.ff_self[3].weight), self.ff_self[3].bias, res=a)
+        return lin(f, self.ff_self[3].weight, self.ff_self[3].bias, a)
 
 
 class _DoubleConvBase(nn.Module):

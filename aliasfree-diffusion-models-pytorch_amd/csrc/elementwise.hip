@@ -122,14 +122,14 @@ __global__ void add_k(const float* __restrict__ a, const float* __restrict__ b, 
   AFD_GRID_STRIDE(i, n) y[i] = a[i] + b[i];
 }
 // out[j] = sum_i in[i*cols + j].  256 threads = 32 columns x 8 row groups; fixed order (deterministic)
-__global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int accumulate) {
+__global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, long rs, int accumulate) {
   __shared__ float red[8][33];
   const int j = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
   float s0 = 0.f, s1 = 0.f;
   if (j < cols) {
     int i = g;
-    for (; i + 8 < rows; i += 16) { s0 += in[(long)i * cols + j]; s1 += in[(long)(i + 8) * cols + j]; }
-    if (i < rows) s0 += in[(long)i * cols + j];
+    for (; i + 8 < rows; i += 16) { s0 += in[(long)i * rs + j]; s1 += in[(long)(i + 8) * rs + j]; }
+    if (i < rows) s0 += in[(long)i * rs + j];
   }
   red[g][threadIdx.x & 31] = s0 + s1;
   __syncthreads();
@@ -268,8 +268,13 @@ int afd_add(const float* a, const float* b, float* y, long n, afd_stream_t st) {
 }
 int afd_colsum(const float* in, float* out, int rows, int cols, int accumulate, afd_stream_t st) {
   AFD_REQUIRE(in && out && rows > 0 && cols > 0, "afd_colsum: bad argument");
-  hipLaunchKernelGGL(colsum_k, dim3((cols + 31) / 32), dim3(256), 0, as_stream(st), in, out, rows, cols, accumulate);
+  hipLaunchKernelGGL(colsum_k, dim3((cols + 31) / 32), dim3(256), 0, as_stream(st), in, out, rows, cols, (long)cols, accumulate);
   return check_launch("afd_colsum");
+}
+int afd_colsum_strided(const float* in, long row_stride, float* out, int rows, int cols, int accumulate, afd_stream_t st) {
+  AFD_REQUIRE(in && out && rows > 0 && cols > 0 && row_stride >= cols, "afd_colsum_strided: bad argument");
+  hipLaunchKernelGGL(colsum_k, dim3((cols + 31) / 32), dim3(256), 0, as_stream(st), in, out, rows, cols, row_stride, accumulate);
+  return check_launch("afd_colsum_strided");
 }
 int afd_pos_encoding(const int64_t* t, const float* inv_freq, float* temb, int B, int half, afd_stream_t st) {
   AFD_REQUIRE(t && inv_freq && temb && B > 0 && half > 0, "afd_pos_encoding: bad argument");

@@ -106,7 +106,7 @@ __device__ __forceinline__ float gn_dz(float xh, float dyv, float g, float be, f
   return dyv;
 }
 
-// one wave per (b, c) plane: part[b,c] = {sum dz*xhat, sum dz};  demb[b,c] = sum dy;  dres = dz
+// one wave per (b, c) plane: part[b][0][c] = sum dz*xhat, part[b][1][c] = sum dz;  demb[b,c] = sum dy;  dres = dz
 __global__ __launch_bounds__(256) void gn_bwd_plane(const float* __restrict__ x, const float* __restrict__ dy,
                                                     const float* __restrict__ stats, int C, int HW, long planes,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void gn_bwd_plane(const float* __restrict__ x,
     s1 += dz * xh; s2 += dz; s3 += d;
   }
   s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
-  if (lane == 0) {
-    part[2 * pl] = s1; part[2 * pl + 1] = s2;
+  if (lane == 0) {                                  // partial layout (B, 2, C): [b][0][c] = sum dz*xhat, [b][1][c] = sum dz
+    part[(2 * b) * C + c] = s1; part[(2 * b + 1) * C + c] = s2;
     if (demb) demb[pl] = s3;
   }
 }
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(256) void gn_bwd_sample(const float* __restrict__ p
   float a = 0.f, c2 = 0.f;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float g = gamma[c];
-    a += g * part[2 * (b * C + c) + 1];
-    c2 += g * part[2 * (b * C + c)];
+    a += g * part[(2 * b + 1) * C + c];
+    c2 += g * part[(2 * b) * C + c];
   }
   a = block_sum(a, red);
   c2 = block_sum(c2, red);
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ x,
 // ------------------------------------------------------------------------------------------
 // LayerNorm over C for every pixel of an NCHW tensor (tokens = pixels)
 // ------------------------------------------------------------------------------------------
+// generic-C fallback (three strided passes, L2 re-reads)
 __global__ __launch_bounds__(256) void ln_c_fwd(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ stats,
                                                 int C, int HW, long pixels, float eps,
                                                 const float* __restrict__ gamma, const float* __restrict__ beta) {
@@ -185,6 +186,29 @@ __global__ __launch_bounds__(256) void ln_c_fwd(const float* __restrict__ x, flo
   stats[2 * p] = mean; stats[2 * p + 1] = rstd;
   float* yp = y + b * (long)C * HW + l;
   for (int c = 0; c < C; ++c) yp[(long)c * HW] = (xp[(long)c * HW] - mean) * rstd * gamma[c] + beta[c];
+}
+
+// C known at compile time: the pixel's channel vector lives in registers -> one read, one write
+template <int C>
+__global__ __launch_bounds__(256) void ln_c_fwd_reg(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ stats,
+                                                    int HW, long pixels, float eps,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= pixels) return;
+  const long b = p / HW; const int l = p % HW;
+  const long off = b * (long)C * HW + l;
+  float v[C];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { v[c] = x[off + (long)c * HW]; s += v[c]; }
+  const float mean = s / (float)C;
+  float s2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { const float d = v[c] - mean; s2 += d * d; }
+  const float rstd = 1.0f / sqrtf(s2 / (float)C + eps);
+  stats[2 * p] = mean; stats[2 * p + 1] = rstd;
+#pragma unroll
+  for (int c = 0; c < C; ++c) y[off + (long)c * HW] = (v[c] - mean) * rstd * gamma[c] + beta[c];
 }
 
 __global__ __launch_bounds__(256) void ln_c_bwd_dx(const float* __restrict__ x, const float* __restrict__ dy,
@@ -207,7 +231,32 @@ __global__ __launch_bounds__(256) void ln_c_bwd_dx(const float* __restrict__ x, 
   }
 }
 
-// one wave per (b, c) plane: part[b,c] = {sum_l dy*xhat, sum_l dy}
+// register form: gamma*dy is kept in registers, x is read twice (second read hits L2)
+template <int C>
+__global__ __launch_bounds__(256) void ln_c_bwd_dx_reg(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const float* __restrict__ stats, int HW, long pixels,
+                                                       const float* __restrict__ gamma, float* __restrict__ dx) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= pixels) return;
+  const long b = p / HW; const int l = p % HW;
+  const long off = b * (long)C * HW + l;
+  const float mean = stats[2 * p], rstd = stats[2 * p + 1];
+  float g[C];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    g[c] = gamma[c] * dy[off + (long)c * HW];
+    s1 += g[c]; s2 += g[c] * ((x[off + (long)c * HW] - mean) * rstd);
+  }
+  const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float xh = (x[off + (long)c * HW] - mean) * rstd;
+    dx[off + (long)c * HW] = rstd * (g[c] - m1 - xh * m2);
+  }
+}
+
+// one wave per (b, c) plane: part[b][0][c] = sum_l dy*xhat, part[b][1][c] = sum_l dy
 __global__ __launch_bounds__(256) void ln_c_bwd_plane(const float* __restrict__ x, const float* __restrict__ dy,
                                                       const float* __restrict__ stats, int C, int HW, long planes,
                                                       float* __restrict__ part) {
@@ -224,7 +273,7 @@ __global__ __launch_bounds__(256) void ln_c_bwd_plane(const float* __restrict__ 
     s1 += d * xh; s2 += d;
   }
   s1 = wave_sum(s1); s2 = wave_sum(s2);
-  if (lane == 0) { part[2 * pl] = s1; part[2 * pl + 1] = s2; }
+  if (lane == 0) { const int c = pl % C; part[(2 * b) * C + c] = s1; part[(2 * b + 1) * C + c] = s2; }
 }
 
 static inline int gs_grid(long total, int block = 256) {
@@ -282,7 +331,14 @@ int afd_layernorm_c_fwd(const float* x, float* y, float* stats_out, int B, int C
                         const float* gamma, const float* beta, afd_stream_t st) {
   AFD_REQUIRE(x && y && stats_out && gamma && beta && B > 0 && C > 0 && HW > 0, "afd_layernorm_c_fwd: bad argument");
   const long pixels = (long)B * HW;
-  hipLaunchKernelGGL(ln_c_fwd, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, as_stream(st), x, y, stats_out, C, HW, pixels, eps, gamma, beta);
+  const dim3 grid((unsigned)((pixels + 255) / 256));
+  hipStream_t s = as_stream(st);
+  switch (C) {
+    case 32:  hipLaunchKernelGGL(ln_c_fwd_reg<32>,  grid, dim3(256), 0, s, x, y, stats_out, HW, pixels, eps, gamma, beta); break;
+    case 64:  hipLaunchKernelGGL(ln_c_fwd_reg<64>,  grid, dim3(256), 0, s, x, y, stats_out, HW, pixels, eps, gamma, beta); break;
+    case 128: hipLaunchKernelGGL(ln_c_fwd_reg<128>, grid, dim3(256), 0, s, x, y, stats_out, HW, pixels, eps, gamma, beta); break;
+    default:  hipLaunchKernelGGL(ln_c_fwd, grid, dim3(256), 0, s, x, y, stats_out, C, HW, pixels, eps, gamma, beta);
+  }
   return check_launch("afd_layernorm_c_fwd");
 }
 
@@ -291,7 +347,13 @@ int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int
   AFD_REQUIRE(x && dy && stats && gamma && dx && part && B > 0 && C > 0 && HW > 0, "afd_layernorm_c_bwd: bad argument");
   hipStream_t s = as_stream(st);
   const long pixels = (long)B * HW, planes = (long)B * C;
-  hipLaunchKernelGGL(ln_c_bwd_dx, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, s, x, dy, stats, C, HW, pixels, gamma, dx);
+  const dim3 grid((unsigned)((pixels + 255) / 256));
+  switch (C) {
+    case 32:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<32>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx); break;
+    case 64:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<64>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx); break;
+    case 128: hipLaunchKernelGGL(ln_c_bwd_dx_reg<128>, grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx); break;
+    default:  hipLaunchKernelGGL(ln_c_bwd_dx, grid, dim3(256), 0, s, x, dy, stats, C, HW, pixels, gamma, dx);
+  }
   hipLaunchKernelGGL(ln_c_bwd_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, x, dy, stats, C, HW, planes, part);
   return check_launch("afd_layernorm_c_bwd");
 }

@@ -130,11 +130,46 @@ class FiltAct(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # F6 GroupNorm(1, C) with fused epilogues / fused filtered GELU
 # ---------------------------------------------------------------------------------------------
-def _gn_param_grads(part, B, C):
-    """(B,C,2) partials -> dgamma (C,), dbeta (C,) via the deterministic column sum."""
-    out = torch.empty(C, 2, device=part.device, dtype=torch.float32)
+class _GradMode:
+    """When `inplace` is set (by TrainStep around backward) the weight-gradient kernels ADD straight into
+    the parameters' preallocated `.grad` (FlatParams views) and backward returns None for them: this skips
+    ~180 tiny autograd accumulate-adds and as many allocations per step.  Off by default, so
+    torch.autograd.grad / plain .backward() keep their usual semantics."""
+    inplace = False
+
+
+class inplace_param_grads:
+    def __enter__(self):
+        self.prev, _GradMode.inplace = _GradMode.inplace, True
+
+    def __exit__(self, *a):
+        _GradMode.inplace = self.prev
+
+
+def _direct(*params):
+    """True if every given parameter has a contiguous preallocated .grad we may accumulate into."""
+    if not _GradMode.inplace:
+        return False
+    for q in params:
+        if q is None:
+            continue
+        g = q.grad
+        if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+            return False
+    return True
+
+
+def _gn_param_grads(part, B, C, gamma=None, beta=None):
+    """(B,2,C) partials -> dgamma (C,), dbeta (C,) via the deterministic column sum."""
+    if gamma is not None and _direct(gamma, beta):
+        L = lib()
+        # rows of `part` are 2C wide: column block [0,C) -> dgamma, [C,2C) -> dbeta; accumulate in place
+        L.afd_colsum_strided(_p(part), 2 * C, _p(gamma.grad), B, C, 1, _stream())
+        L.afd_colsum_strided(part.data_ptr() + 4 * C, 2 * C, _p(beta.grad), B, C, 1, _stream())
+        return None, None
+    out = torch.empty(2, C, device=part.device, dtype=torch.float32)
     lib().afd_colsum(_p(part), _p(out), B, 2 * C, 0, _stream())
-    return out[:, 0].contiguous(), out[:, 1].contiguous()
+    return out[0], out[1]
 
 
 class GroupNorm1(torch.autograd.Function):
@@ -166,7 +201,7 @@ class GroupNorm1(torch.autograd.Function):
         demb = torch.empty(B, C, device=x.device, dtype=torch.float32) if ctx.has_emb else None
         lib().afd_groupnorm1_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(beta), _p(res), ctx.act,
                                  _p(dx), _p(dres) if (res is not None and ctx.act == 1) else None, _p(part), _p(demb), _stream())
-        dgamma, dbeta = _gn_param_grads(part, B, C)
+        dgamma, dbeta = _gn_param_grads(part, B, C, gamma, beta)
         return dx, dgamma, dbeta, dres, demb, None
 
 
@@ -207,7 +242,7 @@ class GroupNormFiltAct(torch.autograd.Function):
         part = torch.empty(B * C * 2 + B * 2, device=x.device, dtype=torch.float32)
         L.afd_groupnorm1_bwd(_p(x), _p(dv), _p(stats), B, C, H * W, _p(gamma), _p(beta), None, 0,
                              _p(dx), None, _p(part), None, _stream())
-        dgamma, dbeta = _gn_param_grads(part, B, C)
+        dgamma, dbeta = _gn_param_grads(part, B, C, gamma, beta)
         return dx, dgamma, dbeta, (dv if res is not None else None), None, None
 
 
@@ -218,7 +253,9 @@ class Conv(torch.autograd.Function):
     """y = conv(x, w) + bias + res.  (The GELU epilogue is only used by `conv_infer`.)"""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res):
+    def forward(ctx, x, w, bias, res, w_param=None, b_param=None):
+        # w may be a reshaped VIEW of a parameter (Linear weights used as 1x1 kernels); w_param / b_param are
+        # the leaf Parameters whose .grad the in-place mode accumulates into
         _chk(x, w, bias, res)
         x, w, res = _c(x), _c(w), _c(res)
         B, Cin, H, W = x.shape
@@ -227,6 +264,7 @@ class Conv(torch.autograd.Function):
         lib().afd_conv_fwd(_p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Cout, H, W, ks, 0, _stream())
         ctx.save_for_backward(x, w)
         ctx.has_bias, ctx.has_res = bias is not None, res is not None
+        ctx.w_param, ctx.b_param = w_param, b_param
         return y
 
     @staticmethod
@@ -241,16 +279,26 @@ class Conv(torch.autograd.Function):
             dx = torch.empty_like(x)
             L.afd_conv_dgrad(_p(dy), _p(w), _p(dx), B, Cin, Cout, H, W, ks, _stream())
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty_like(w)
-            db = torch.empty(Cout, device=x.device, dtype=torch.float32) if ctx.has_bias else None
             nbytes = L.afd_conv_wgrad_workspace_bytes(B, Cin, Cout, H, W, ks)
             ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
-            L.afd_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), B, Cin, Cout, H, W, ks, 0, _p(ws), _stream())
-        return dx, dw, db, (dy if ctx.has_res else None)
+            wp, bp = ctx.w_param, ctx.b_param
+            if _direct(wp, bp) and wp.grad.numel() == w.numel():
+                L.afd_conv_wgrad(_p(x), _p(dy), _p(wp.grad), _p(bp.grad) if bp is not None else None,
+                                 B, Cin, Cout, H, W, ks, 1, _p(ws), _stream())
+            else:
+                dw = torch.empty_like(w)
+                db = torch.empty(Cout, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+                L.afd_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), B, Cin, Cout, H, W, ks, 0, _p(ws), _stream())
+        return dx, dw, db, (dy if ctx.has_res else None), None, None
 
 
-def conv(x, w, bias=None, res=None):
-    return Conv.apply(x, w, bias, res)
+def conv(x, w, bias=None, res=None, w_param=None, b_param=None):
+    """w_param / b_param: the leaf Parameters behind `w` / `bias` (enables in-place grad accumulation)."""
+    if w_param is None and isinstance(w, torch.nn.Parameter):
+        w_param = w
+    if b_param is None and isinstance(bias, torch.nn.Parameter):
+        b_param = bias
+    return Conv.apply(x, w, bias, res, w_param, b_param)
 
 
 def conv_infer(x, w, bias=None, res=None, act=0):
@@ -279,6 +327,7 @@ class LayerNormC(torch.autograd.Function):
         stats = torch.empty(B, H * W, 2, device=x.device, dtype=torch.float32)
         lib().afd_layernorm_c_fwd(_p(x), _p(y), _p(stats), B, C, H * W, LN_EPS, _p(gamma), _p(beta), _stream())
         ctx.save_for_backward(x, gamma, stats)
+        ctx.beta_param = beta
         return y
 
     @staticmethod
@@ -287,9 +336,9 @@ class LayerNormC(torch.autograd.Function):
         B, C, H, W = x.shape
         dy = _c(dy)
         dx = torch.empty_like(x)
-        part = torch.empty(B, C, 2, device=x.device, dtype=torch.float32)
+        part = torch.empty(B, 2, C, device=x.device, dtype=torch.float32)
         lib().afd_layernorm_c_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(dx), _p(part), _stream())
-        dgamma, dbeta = _gn_param_grads(part, B, C)
+        dgamma, dbeta = _gn_param_grads(part, B, C, gamma, ctx.beta_param)
         return dx, dgamma, dbeta
 
 
@@ -433,6 +482,7 @@ class SiluLinear(torch.autograd.Function):
         out = torch.empty(B, N, device=temb.device, dtype=torch.float32)
         lib().afd_silu_linear_fwd(_p(temb), _p(w), _p(bias), _p(out), B, K, N, _stream())
         ctx.save_for_backward(temb, w)
+        ctx.params = (w if isinstance(w, torch.nn.Parameter) else None, bias if isinstance(bias, torch.nn.Parameter) else None)
         return out
 
     @staticmethod
@@ -441,9 +491,13 @@ class SiluLinear(torch.autograd.Function):
         B, K = temb.shape
         N = w.shape[0]
         dout = _c(dout)
+        dtemb = torch.zeros_like(temb) if ctx.needs_input_grad[0] else None
+        wp, bp = ctx.params
+        if _direct(wp, bp):
+            lib().afd_silu_linear_bwd(_p(temb), _p(w), _p(dout), _p(wp.grad), _p(bp.grad), _p(dtemb), B, K, N, 1, _stream())
+            return dtemb, None, None
         dw = torch.empty_like(w)
         db = torch.empty(N, device=w.device, dtype=torch.float32)
-        dtemb = torch.zeros_like(temb) if ctx.needs_input_grad[0] else None
         lib().afd_silu_linear_bwd(_p(temb), _p(w), _p(dout), _p(dw), _p(db), _p(dtemb), B, K, N, 0, _stream())
         return dtemb, dw, db
 

@@ -149,7 +149,8 @@ class TrainStep:
         pred = self.model(x_t, t)
         loss = ops.mse_loss(noise, pred)
         self.opt.zero_grad()
-        loss.backward()
+        with ops.inplace_param_grads():          # weight-gradient kernels add straight into the flat .grad views
+            loss.backward()
         scale = self.ddp() if self.ddp is not None else 1.0
         self.opt.step(grad_scale=scale)
         return loss.detach()

@@ -135,13 +135,16 @@ def kernel_table(dev, B):
     return out, rows
 
 
-def cpu_baseline(steps=2, B=16):
-    """The CPU oracle's train step (fwd + autograd bwd + AdamW) on the host cores, Config D, B=16."""
+def cpu_baseline(steps=6, B=64):
+    """The CPU oracle's train step (fwd + autograd bwd + AdamW) on the host cores, Config D, a bounded
+    sample of the same workload (B=64 instead of 256 per step; ~10-20 s of CPU work)."""
+    import contextlib, io
     import afdm
     from oracle import ref_ops as R
     torch.set_num_threads(host_threads())
     afdm.set_seed(42)
-    net = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device="cpu", variant=3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device="cpu", variant=3)
     sd = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
     m = {k: torch.zeros_like(v) for k, v in sd.items()}
     v2 = {k: torch.zeros_like(v) for k, v in sd.items()}

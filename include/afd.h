@@ -80,8 +80,9 @@ int afd_filt_act_bwd(const float* x, const float* dy, float* dv, int B, int C, i
  *   act  0 = identity, 1 = exact GELU (nn.GELU, :86 / F.gelu, :93);
  *   emb  (B,C) or NULL     : time-embedding add of Down/Up (:218-219, :244-245).
  * bwd: given dy (= dL/dy) recomputes the chain; writes dx, dres (may be NULL), and per-sample
- *   partials {sum dz*xhat, sum dz} per (b,c) for dgamma/dbeta, which afd_colsum reduces over b.
- *   The partial buffer must hold B*C*2 + B*2 floats (the tail is scratch).  demb = sum_hw dy is (B,C). */
+ *   partials laid out (B, 2, C): [b][0][c] = sum dz*xhat (-> dgamma), [b][1][c] = sum dz (-> dbeta), which
+ *   afd_colsum reduces over b into a (2, C) row pair.  The partial buffer must hold B*C*2 + B*2 floats (the
+ *   tail is scratch).  demb = sum_hw dy is (B,C). */
 int afd_groupnorm1_fwd(const float* x, float* y, float* stats_out, int B, int C, int HW, float eps,
                        const float* gamma, const float* beta, const float* res, int act, const float* emb,
                        afd_stream_t stream);
@@ -91,6 +92,8 @@ int afd_groupnorm1_bwd(const float* x, const float* dy, const float* stats, int 
                        afd_stream_t stream);
 /* out[j] (+)= sum_i in[i*cols + j], i < rows (deterministic tree; accumulate != 0 adds into out) */
 int afd_colsum(const float* in, float* out, int rows, int cols, int accumulate, afd_stream_t stream);
+/* same with an explicit row stride (elements): sums a column block of a wider matrix */
+int afd_colsum_strided(const float* in, long row_stride, float* out, int rows, int cols, int accumulate, afd_stream_t stream);
 
 /* ---- F5/F10: convolution as implicit GEMM (3x3 pad 1, or 1x1) --------- ddpm_utils.py:84,87,112,115;
  *      nn.Linear / MHA projections on NCHW tokens (ddpm_utils.py:59-66,71,73); outc (ddpm_models.py:84)
@@ -116,7 +119,7 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias /* o
 int afd_layernorm_c_fwd(const float* x, float* y, float* stats_out, int B, int C, int HW, float eps,
                         const float* gamma, const float* beta, afd_stream_t stream);
 int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
-                        const float* gamma, float* dx, float* dgamma_dbeta_partial /* (B,C,2) */,
+                        const float* gamma, float* dx, float* dgamma_dbeta_partial /* (B,2,C) */,
                         afd_stream_t stream);
 
 /* ---- F10: multi-head self-attention core (softmax(QK^T/sqrt(d))V), flash-style ------------------
