@@ -427,37 +427,99 @@ __global__ __launch_bounds__(256) void conv_mfma_sk(const float* __restrict__ x,
 }
 
 // ------------------------------------------------------------------------------------------
-// wgrad: part[split][cout][cin][tap] = sum_{pixels of the split} dY[cout][p] * X[cin][p + tap]
+// wgrad: part[slab][cout][cin][tap] = sum_{pixels of the slab} dY[cout][p] * X[cin][p + tap]
+//   A = dY tile (rows = out channels, k = pixel), B = haloed X tile (columns = in channels), one
+//   accumulator tile per tap.  A workgroup owns a (32*WNn couts) x (32*WCn cins) block and a range of
+//   64-pixel chunks; its 4 waves are arranged WNn x WCn x WK: with fewer than 64 channels on a side the
+//   spare waves split the pixels of every chunk (WK) and write their own slab, so no wave idles.
+//   All 256 threads stage (lane = 32 consecutive tile positions -> 128-B reads); every load of a chunk
+//   is issued before the first wait, and chunk k+1 is fetched while chunk k's 288 MFMAs run.
 // ------------------------------------------------------------------------------------------
-template <int T>
+template <int T, int WNn, int WCn, int NPB>
 __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ dy,
                                                        float* __restrict__ part, int B, int Cin, int Cout, int H, int W,
                                                        int chunks_per_split, int nchunks, TileGeom g) {
   constexpr int PT = 64, HALO = (T == 9) ? 1 : 0, S1 = PT + 1;
+  constexpr int WK = 4 / (WNn * WCn), BNo = 32 * WNn, BCi = 32 * WCn;
+  constexpr int NG = BNo / 4;                        // dY rows per thread
+  constexpr int NM = BCi / 8;                        // channels per thread per position slot
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int XSP = g.XS | 1;                          // odd channel stride
-  float* Gs = smem;                                  // [64][S1]   dY tile (cout rows)
-  float* Xs = smem + 64 * S1;                        // [64][XSP]  X tile (cin rows, haloed)
-  int* Po = reinterpret_cast<int*>(Xs + 64 * XSP);   // [PT] pixel -> LDS offset
+  const int XSP = g.XS | 1;                          // odd channel stride: conflict-free fragment reads
+  float* Gs = smem;                                  // [BNo][S1]   dY tile
+  float* Xs = smem + BNo * S1;                       // [BCi][XSP]  X tile (haloed)
+  int* Po = reinterpret_cast<int*>(Xs + BCi * XSP);  // [PT] pixel -> LDS offset
   const int HW = H * W;
   const long P = (long)B * HW;
-  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, split = blockIdx.z;
+  const int n0 = blockIdx.x * BNo, c0 = blockIdx.y * BCi, split = blockIdx.z;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int nw = (wv >> 1) * 32, cw = (wv & 1) * 32;
+  const int wn = wv % WNn, wc = (wv / WNn) % WCn, wk = wv / (WNn * WCn);
+  const int nw = wn * 32, cw = wc * 32;
   const int half = lane >> 5, l31 = lane & 31;
   const bool active = (n0 + nw < Cout) && (c0 + cw < Cin);             // wave-uniform
 
   if (threadIdx.x < PT) Po[threadIdx.x] = pix_lds_off(threadIdx.x, W, g, HALO);
 
-  // staging plans (chunk-invariant).  dY: thread owns tile pixel pp = tid % 64, rows tid/64 + 4e.
-  const int pp = threadIdx.x & 63;
-  const int gdb = (HW >= PT) ? 0 : pp / HW;                             // image delta inside the tile
-  const int gpix = (HW >= PT) ? pp : pp % HW;                           // pixel inside the image (+ chunk base when HW >= PT)
-  // X: thread owns LDS position xpos = tid % npos of channel group tid / npos
-  const int npos = g.XS;
-  const int ngrp = 256 / npos > 0 ? 256 / npos : 1;
-  const int xgrp = threadIdx.x / npos, xpos = threadIdx.x % npos;
-  const bool xact = (npos <= 256) ? (xgrp < ngrp) : true;
+  // ---- chunk-invariant staging plan
+  const int pp = threadIdx.x & 63, ng = threadIdx.x >> 6;               // dY: pixel pp, rows ng + 4e
+  const int gdb = (HW >= PT) ? 0 : pp / HW;
+  const int gpix = (HW >= PT) ? pp : pp % HW;
+  const int px = threadIdx.x & 31, cg = threadIdx.x >> 5;               // X: position px + 32e, channels cg + 8m
+  int p_ti[NPB], p_rr[NPB], p_cc[NPB];
+#pragma unroll
+  for (int e = 0; e < NPB; ++e) {
+    const int pos = px + 32 * e;
+    const int ti = pos / g.BS, rem = pos % g.BS;
+    p_ti[e] = pos < g.XS ? ti : -1;
+    p_rr[e] = rem / g.Wp - HALO;
+    p_cc[e] = rem % g.Wp - HALO;
+  }
+
+  float gv[NG], xv[NPB][NM];
+  unsigned gok, xok[NPB];
+  auto fetch = [&](int ch) {
+    const long pc = (long)ch * PT;
+    {  // dY
+      const long b = pc / HW + gdb;
+      const int pix = (HW >= PT) ? (int)(pc % HW) + gpix : gpix;
+      const bool pin = (pc + pp) < P;
+      const unsigned gb = pin ? (unsigned)(b * Cout) * (unsigned)HW + (unsigned)pix : 0u;
+      gok = 0;
+#pragma unroll
+      for (int e = 0; e < NG; ++e) {
+        const int n = n0 + ng + 4 * e;
+        gv[e] = dy[gb + (unsigned)(min(n, Cout - 1) * HW)];
+        gok |= ((pin && n < Cout) ? 1u : 0u) << e;
+      }
+    }
+    const long img0 = pc / HW;
+    const int row0 = (int)((pc % HW) / W);
+#pragma unroll
+    for (int e = 0; e < NPB; ++e) {
+      xok[e] = 0;
+      if (p_ti[e] >= 0) {
+        const long img = img0 + p_ti[e];
+        const int yy = row0 + p_rr[e];
+        const bool ok = p_cc[e] >= 0 && p_cc[e] < W && yy >= 0 && yy < H && img * HW < P;
+        const unsigned xb = ok ? (unsigned)(img * Cin) * (unsigned)HW + (unsigned)(yy * W + p_cc[e]) : 0u;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          const int c = c0 + cg + 8 * m;
+          xv[e][m] = x[xb + (unsigned)(min(c, Cin - 1) * HW)];
+          xok[e] |= ((ok && c < Cin) ? 1u : 0u) << m;
+        }
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int e = 0; e < NG; ++e) Gs[(ng + 4 * e) * S1 + pp] = ((gok >> e) & 1u) ? gv[e] : 0.f;
+#pragma unroll
+    for (int e = 0; e < NPB; ++e)
+      if (p_ti[e] >= 0) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) Xs[(cg + 8 * m) * XSP + px + 32 * e] = ((xok[e] >> m) & 1u) ? xv[e][m] : 0.f;
+      }
+  };
 
   f32x16 acc[T];
 #pragma unroll
@@ -467,54 +529,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
 
   const int cbeg = split * chunks_per_split;
   const int cend = min(nchunks, cbeg + chunks_per_split);
+  if (cbeg < cend) fetch(cbeg);
   for (int ch = cbeg; ch < cend; ++ch) {
-    const long pc = (long)ch * PT;                   // first global pixel of the chunk
     __syncthreads();
-    {  // dY tile
-      const long b = pc / HW + gdb;
-      const int pix = (HW >= PT) ? (int)(pc % HW) + gpix : gpix;
-      const bool pin = (pc + pp) < P;
-      const long gb = pin ? b * Cout * (long)HW + pix : 0;
-      float gv_[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) gv_[e] = dy[gb + (long)min(n0 + (int)(threadIdx.x >> 6) + 4 * e, Cout - 1) * HW];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int n = (threadIdx.x >> 6) + 4 * e;
-        Gs[n * S1 + pp] = (pin && n0 + n < Cout) ? gv_[e] : 0.f;
-      }
-    }
-    if (npos <= 256) {
-      if (xact) {
-        long img; int off;
-        pos_source(xpos, pc, H, W, P, g, HALO, img, off);
-        const long xb = off >= 0 ? img * Cin * (long)HW + off : 0;
-        for (int j0 = xgrp; j0 < 64; j0 += 8 * ngrp) {
-          float xv_[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) xv_[u] = x[xb + (long)min(c0 + j0 + u * ngrp, Cin - 1) * HW];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int j = j0 + u * ngrp;
-            if (j < 64) Xs[j * XSP + xpos] = (off >= 0 && c0 + j < Cin) ? xv_[u] : 0.f;
-          }
-        }
-      }
-    } else {
-      for (int pos = threadIdx.x; pos < npos; pos += 256) {
-        long img; int off;
-        pos_source(pos, pc, H, W, P, g, HALO, img, off);
-        for (int j = 0; j < 64; ++j) {
-          float v = 0.f;
-          if (off >= 0 && c0 + j < Cin) v = x[(img * Cin + c0 + j) * (long)HW + off];
-          Xs[j * XSP + pos] = v;
-        }
-      }
-    }
+    commit();
     __syncthreads();
+    if (ch + 1 < cend) fetch(ch + 1);                                   // in flight during the MFMAs
     if (active) {
-#pragma unroll 4
-      for (int s = 0; s < PT / 2; ++s) {
+#pragma unroll 2
+      for (int s = wk * (PT / 2 / WK); s < (wk + 1) * (PT / 2 / WK); ++s) {
         const int pix = 2 * s + half;
         const float a = Gs[(nw + l31) * S1 + pix];
         const int xo = (cw + l31) * XSP + Po[pix];
@@ -526,31 +549,64 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
       }
     }
   }
-  if (!active) return;
   float* out = part + (long)split * Cout * Cin * T;
-  const int ci = c0 + cw + l31;
-  if (ci < Cin) {
+  if (WK == 1) {
+    if (!active) return;
+    const int ci = c0 + cw + l31;
+    if (ci < Cin) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + nw + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (n >= Cout) continue;
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + nw + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (n >= Cout) continue;
 #pragma unroll
-      for (int t = 0; t < T; ++t) out[((long)n * Cin + ci) * T + t] = acc[t][r];
+        for (int t = 0; t < T; ++t) out[((long)n * Cin + ci) * T + t] = acc[t][r];
+      }
+    }
+  } else {
+    // the WK waves that share an output block meet in LDS, one tap at a time (fixed order: deterministic)
+    float* red = smem;                                  // [4 waves][16][64]
+    constexpr int NB = WNn * WCn;                       // distinct output blocks in this workgroup (1 or 2)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wv * 16 + r) * 64 + lane] = acc[t][r];
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < NB * 1024; idx += 256) {
+        const int blk = idx / 1024, r = (idx / 64) % 16, ln = idx % 64;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < WK; ++k) v += red[((k * NB + blk) * 16 + r) * 64 + ln];   // wave id = k*NB + blk
+        const int bn = blk % WNn, bc = blk / WNn;
+        const int n = n0 + bn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int ci = c0 + bc * 32 + (ln & 31);
+        if (n < Cout && ci < Cin) out[((long)n * Cin + ci) * T + t] = v;
+      }
     }
   }
 }
 
+// dw[i] (+)= sum_k part[k][i]: 256 threads = 32 consecutive elements x 8 slab groups (fixed order)
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, long n, int splits, int accumulate) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // 4 independent chains: the loads overlap
-    int k = 0;
-    for (; k + 4 <= splits; k += 4) {
-      s0 += part[(long)k * n + i]; s1 += part[(long)(k + 1) * n + i];
-      s2 += part[(long)(k + 2) * n + i]; s3 += part[(long)(k + 3) * n + i];
+  __shared__ float red[8][33];
+  const long i = (long)blockIdx.x * 32 + (threadIdx.x & 31);
+  const int g = threadIdx.x >> 5;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int k = g;
+    for (; k + 24 < splits; k += 32) {
+      s0 += part[(long)k * n + i]; s1 += part[(long)(k + 8) * n + i];
+      s2 += part[(long)(k + 16) * n + i]; s3 += part[(long)(k + 24) * n + i];
     }
-    for (; k < splits; ++k) s0 += part[(long)k * n + i];
-    const float s = (s0 + s1) + (s2 + s3);
-    dw[i] = accumulate ? dw[i] + s : s;
+    for (; k < splits; k += 8) s0 += part[(long)k * n + i];
+  }
+  red[g][threadIdx.x & 31] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+    dw[i] = accumulate ? dw[i] + t : t;
   }
 }
 
@@ -598,13 +654,42 @@ static int launch_mfma(const float* x, const float* w, const float* bias, const 
   return 0;
 }
 
-static inline int wgrad_splits(int B, int Cin, int Cout, int H, int W) {
-  const long nchunks = ((long)B * H * W + 63) / 64;
-  const long tiles = (long)((Cout + 63) / 64) * ((Cin + 63) / 64);
-  long s = 512 / tiles;                 // ~2 workgroups per CU is enough; more splits only add partial-slab traffic
+struct WgradPlan { int wnn, wcn, wk, splits, slabs, nchunks, cps, npb; };
+static inline WgradPlan wgrad_plan(int B, int Cin, int Cout, int H, int W, int ksize) {
+  WgradPlan p;
+  p.wnn = Cout > 32 ? 2 : 1;
+  p.wcn = Cin > 32 ? 2 : 1;
+  p.wk = 4 / (p.wnn * p.wcn);
+  p.nchunks = (int)(((long)B * H * W + 63) / 64);
+  const long tiles = (long)((Cout + 32 * p.wnn - 1) / (32 * p.wnn)) * ((Cin + 32 * p.wcn - 1) / (32 * p.wcn));
+  long s = 256 / tiles;                     // one workgroup per CU: the kernel is register-heavy (1 wave/SIMD)
   if (s < 1) s = 1;
-  if (s > nchunks) s = nchunks;
-  return (int)s;
+  if (s > p.nchunks) s = p.nchunks;
+  p.cps = (int)((p.nchunks + s - 1) / s);
+  p.splits = (int)((p.nchunks + p.cps - 1) / p.cps);   // no empty splits
+  p.slabs = p.splits;                                  // pixel-split waves meet in LDS: one slab per split
+  const TileGeom g = make_geom(H, W, 64, ksize == 3 ? 1 : 0);
+  const int need = (g.XS + 31) / 32;
+  p.npb = ksize == 1 ? 2 : (need <= 4 ? 4 : (need <= 5 ? 5 : 8));
+  return p;
+}
+
+template <int T, int WNn, int WCn, int NPB>
+static void launch_wgrad(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W,
+                         const WgradPlan& p, const TileGeom& g, hipStream_t s) {
+  size_t lds = sizeof(float) * ((size_t)32 * WNn * 65 + (size_t)32 * WCn * (g.XS | 1)) + sizeof(int) * 64;
+  if (WNn * WCn < 4 && lds < sizeof(float) * 4 * 16 * 64) lds = sizeof(float) * 4 * 16 * 64;      // cross-wave reduce buffer
+  const dim3 grid((Cout + 32 * WNn - 1) / (32 * WNn), (Cin + 32 * WCn - 1) / (32 * WCn), p.splits);
+  hipLaunchKernelGGL((conv_wgrad_mfma<T, WNn, WCn, NPB>), grid, dim3(256), lds, s, x, dy, part, B, Cin, Cout, H, W, p.cps, p.nchunks, g);
+}
+
+template <int T, int NPB>
+static void launch_wgrad_roles(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W,
+                               const WgradPlan& p, const TileGeom& g, hipStream_t s) {
+  if (p.wnn == 2 && p.wcn == 2) launch_wgrad<T, 2, 2, NPB>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
+  else if (p.wnn == 2) launch_wgrad<T, 2, 1, NPB>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
+  else if (p.wcn == 2) launch_wgrad<T, 1, 2, NPB>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
+  else launch_wgrad<T, 1, 1, NPB>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
 }
 
 }  // namespace afd
@@ -655,7 +740,7 @@ int afd_conv_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, i
 size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ksize) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
   if (!tile_ok(H, W, 64)) return sizeof(float) * (size_t)B * Cout;
-  return sizeof(float) * ((size_t)wgrad_splits(B, Cin, Cout, H, W) * Cout * Cin * ksize * ksize + (size_t)B * Cout);
+  return sizeof(float) * ((size_t)wgrad_plan(B, Cin, Cout, H, W, ksize).slabs * Cout * Cin * ksize * ksize + (size_t)B * Cout);
 }
 
 int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
@@ -665,18 +750,16 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
   hipStream_t s = as_stream(st);
   const int T = ksize * ksize;
   const TileGeom g = make_geom(H, W, 64, ksize == 3 ? 1 : 0);
-  if (tile_ok(H, W, 64) && g.XS <= 1024) {
+  if (tile_ok(H, W, 64) && g.XS <= 256 && (long)B * H * W * (Cin > Cout ? Cin : Cout) < (1L << 31)) {
     AFD_REQUIRE(workspace, "afd_conv_wgrad: workspace is NULL");
-    const int splits = wgrad_splits(B, Cin, Cout, H, W);
-    const int nchunks = (int)(((long)B * H * W + 63) / 64);
-    const int cps = (nchunks + splits - 1) / splits;
-    const size_t lds = sizeof(float) * (64 * 65 + 64 * (size_t)(g.XS | 1)) + sizeof(int) * 64;
-    const dim3 grid((Cout + 63) / 64, (Cin + 63) / 64, splits);
+    const WgradPlan p = wgrad_plan(B, Cin, Cout, H, W, ksize);
     float* part = static_cast<float*>(workspace);
-    if (ksize == 3) hipLaunchKernelGGL(conv_wgrad_mfma<9>, grid, dim3(256), lds, s, x, dy, part, B, Cin, Cout, H, W, cps, nchunks, g);
-    else hipLaunchKernelGGL(conv_wgrad_mfma<1>, grid, dim3(256), lds, s, x, dy, part, B, Cin, Cout, H, W, cps, nchunks, g);
+    if (ksize == 1) launch_wgrad_roles<1, 2>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
+    else if (p.npb == 4) launch_wgrad_roles<9, 4>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
+    else if (p.npb == 5) launch_wgrad_roles<9, 5>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
+    else launch_wgrad_roles<9, 8>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
     const long n = (long)Cout * Cin * T;
-    hipLaunchKernelGGL(wgrad_reduce, dim3(gs_grid(n)), dim3(256), 0, s, part, dw, n, splits, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, part, dw, n, p.slabs, accumulate);
   } else {
     const dim3 grid((unsigned)(Cout * Cin));
     if (ksize == 3) hipLaunchKernelGGL(conv_direct_wgrad<3>, grid, dim3(256), 0, s, x, dy, dw, B, Cin, Cout, H, W, accumulate);
