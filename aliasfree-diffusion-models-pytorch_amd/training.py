@@ -133,27 +133,37 @@ class GradAllReduce:
 class TrainStep:
     """The reference's per-batch body (ddpm_utils.py:499-507) as one callable:
          t -> noise_images -> UNet -> MSE -> zero_grad -> backward -> [all-reduce] -> AdamW.
-    `graph=True` captures everything from noise_images to AdamW into a hipGraph on first use (static
-    shapes); the CPU-generator timestep draw and the H2D copies stay outside the graph."""
+    `graph=True` captures the device work into a hipGraph on first use (static shapes): the whole step on
+    one GPU; with data parallelism everything up to and including backward -- the gradient all-reduce
+    (one 23.6 MB exchange) and AdamW then run after the replay.  The CPU-generator timestep draw and the
+    H2D copies always stay outside the graph."""
 
     def __init__(self, model, diffusion, lr, graph=False, distributed=None, n_buckets=4):
         self.model, self.diffusion = model, diffusion
         self.opt = FusedAdamW(model, lr=lr)
-        self.ddp = GradAllReduce(self.opt.fp.grad, n_buckets) if (distributed if distributed is not None else dist.is_initialized()) else None
-        self.use_graph = graph and self.ddp is None
+        want_ddp = distributed if distributed is not None else dist.is_initialized()
+        self.ddp = GradAllReduce(self.opt.fp.grad, n_buckets) if want_ddp else None
+        self.use_graph = graph
         self._graph = None
         self._static = None
 
-    def _body(self, images, t, eps):
+    def _fwd_bwd(self, images, t, eps):
         x_t, noise = self.diffusion.noise_images(images, t, eps)
         pred = self.model(x_t, t)
         loss = ops.mse_loss(noise, pred)
         self.opt.zero_grad()
         with ops.inplace_param_grads():          # weight-gradient kernels add straight into the flat .grad views
             loss.backward()
+        return loss.detach()
+
+    def _update(self):
         scale = self.ddp() if self.ddp is not None else 1.0
         self.opt.step(grad_scale=scale)
-        return loss.detach()
+
+    def _body(self, images, t, eps):
+        loss = self._fwd_bwd(images, t, eps)
+        self._update()
+        return loss
 
     def __call__(self, images, t=None, eps=None):
         """images (B,C,S,S) on the device; t (B,) int64 [default: diffusion.sample_timesteps];
@@ -163,23 +173,27 @@ class TrainStep:
         t = t.to(images.device, non_blocking=True)
         if not self.use_graph:
             return self._body(images, t, eps)
+        whole = self.ddp is None                    # single GPU: AdamW is captured too
         if self._graph is None:
             self._static = {"images": images.clone(), "t": t.clone(), "eps": None if eps is None else eps.clone()}
+            st = self._static
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 for _ in range(2):                      # warm-up outside capture (allocator, lazy init)
-                    self._body(self._static["images"], self._static["t"], self._static["eps"])
+                    self._body(st["images"], st["t"], st["eps"])
             torch.cuda.current_stream().wait_stream(s)
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
-                self._static["loss"] = self._body(self._static["images"], self._static["t"], self._static["eps"])
+                st["loss"] = (self._body if whole else self._fwd_bwd)(st["images"], st["t"], st["eps"])
         st = self._static
         st["images"].copy_(images)
         st["t"].copy_(t)
         if eps is not None:
             st["eps"].copy_(eps)
         self._graph.replay()
+        if not whole:
+            self._update()
         return st["loss"]
 
 

@@ -187,8 +187,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("AFD_DIST_BACKEND", "nccl"))     # nccl = RCCL over xGMI
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    local = local % max(1, torch.cuda.device_count())        # (tests may stack ranks on one GPU with gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -200,7 +201,7 @@ def main():
         model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET) if args.variant else None,
                           device=dev, variant=args.variant).to(dev)
     diff = afdm.Diffusion(noise_steps=1000, img_size=32, device=dev)
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = not args.no_graph
     step = afdm.TrainStep(model, diff, lr=3e-4, graph=use_graph, distributed=(world > 1))
     g = torch.Generator().manual_seed(42 + rank)
     images = (torch.rand(args.batch, 3, 32, 32, generator=g) * 2 - 1).to(dev)
@@ -222,7 +223,7 @@ def main():
             raise
         print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
         graph_ok = False
-        step = afdm.TrainStep(model, diff, lr=3e-4, graph=False, distributed=False)
+        step = afdm.TrainStep(model, diff, lr=3e-4, graph=False, distributed=(world > 1))
         for _ in range(args.warmup):
             loss = step(images)
     sync()
