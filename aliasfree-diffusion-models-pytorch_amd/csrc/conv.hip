@@ -200,11 +200,7 @@ __device__ __forceinline__ void pos_source(int pos, long p0, int H, int W, long 
 //   FWD:   k = cin,  n = cout, w index ((n*K + k)*T + t)
 //   DGRAD: k = cout, n = cin,  w index ((k*N + n)*T + (T-1-t))   (taps flipped)
 // ------------------------------------------------------------------------------------------
-// Register staging shared by conv_mfma / conv_mfma_sk: every thread owns NW weight elements and up
-// to NP x KC activation elements of a K chunk.  `fetch` issues ALL their global loads back to back
-// (clamped addresses, no branches); `commit` writes them to LDS with the out-of-range ones zeroed.
-// The main loop fetches chunk k+1 before the MFMAs of chunk k, so the load latency hides behind
-// the matrix work even with a single resident workgroup (async-stage split).
+// Register staging for conv_mfma_sk (generic form: addresses recomputed per chunk).
 template <int T, bool DGRAD, int BN, int KC, int NP>
 struct Stager {
   static constexpr int WS = KC * T + 1;
@@ -262,18 +258,35 @@ struct Stager {
   }
 };
 
-template <int T, bool DGRAD, int BN, int KC>
+// compile-time tile geometry for the square maps of the UNet (PT = 128): {XS, Wp}; GEO 0 = run-time
+template <int GEO> struct Geo { static constexpr int XS = 0, Wp = 0; };
+template <> struct Geo<1> { static constexpr int XS = 204, Wp = 34; };   // 32x32: 4 rows      (6 x 34)
+template <> struct Geo<2> { static constexpr int XS = 180, Wp = 18; };   // 16x16: 8 rows      (10 x 18)
+template <> struct Geo<3> { static constexpr int XS = 200, Wp = 10; };   // 8x8:   2 images    (2 x 10 x 10)
+template <> struct Geo<4> { static constexpr int XS = 288, Wp = 6; };    // 4x4:   8 images    (8 x 6 x 6)
+template <> struct Geo<5> { static constexpr int XS = 128, Wp = 0; };    // 1x1 convolution: no halo, any map
+
+// Main forward / dgrad kernel.
+//  * per-thread staging PLAN (source offsets, LDS destinations, validity) is computed once; per K chunk
+//    only a wave-uniform base moves, so a global load costs no vector ALU work;
+//  * with a compile-time geometry every LDS fragment address is lane_base + immediate;
+//  * two LDS buffers: chunk k+1 is written while chunk k is multiplied, ONE barrier per chunk, and the
+//    global loads of chunk k+2 are in flight meanwhile.
+template <int T, bool DGRAD, int BN, int KC, int GEO>
 __global__ __launch_bounds__(256) void conv_mfma(const float* __restrict__ x, const float* __restrict__ w,
                                                  const float* __restrict__ bias, const float* __restrict__ res,
                                                  float* __restrict__ y, int B, int K, int N, int H, int W, int act,
                                                  TileGeom g) {
   constexpr int PT = 128, HALO = (T == 9) ? 1 : 0;
-  constexpr int TM = (BN == 64) ? 2 : 1;            // 32-pixel MFMA tiles per wave
+  constexpr int TM = (BN == 64) ? 2 : 1;            // 32-pixel MFMA tiles per wave (waves: 2x2 or 1x4)
   constexpr int WS = KC * T + 1;                    // odd row stride of the weight image
   constexpr int NP = (T == 9) ? 2 : 1;              // LDS positions per thread (XS <= 512 / <= 256)
+  constexpr int NW = BN * KC * T / 256;
+  static_assert(BN * KC * T % 256 == 0, "weight chunk must divide over 256 threads");
+  const int XS = GEO ? Geo<GEO>::XS : g.XS;
+  const int Wp = GEO ? Geo<GEO>::Wp : g.Wp;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ws = smem;                                  // [BN][WS]
-  float* Xs = smem + BN * WS;                        // [KC][g.XS]
+  const int BUF = BN * WS + KC * XS;                 // floats per LDS buffer: [BN][WS] weights, [KC][XS] activations
   const int HW = H * W;
   const long P = (long)B * HW;
   const long p0 = (long)blockIdx.y * PT;
@@ -283,17 +296,72 @@ __global__ __launch_bounds__(256) void conv_mfma(const float* __restrict__ x, co
   const int mw = (BN == 64) ? (wv & 1) * 64 : wv * 32;                  // wave's first pixel in the tile
   const int half = lane >> 5, l31 = lane & 31;
 
-  // chunk-invariant staging plan for X
-  int spos[NP], soff[NP]; long simg[NP];
+  // ---- staging plan (chunk-invariant)
+  unsigned wsrc[NW]; int wdst[NW]; unsigned wmask = 0;
+  int wkc[NW];
+#pragma unroll
+  for (int e = 0; e < NW; ++e) {
+    const int i = threadIdx.x + 256 * e;
+    int n, kc, t;
+    if (!DGRAD) { n = i / (KC * T); const int r = i % (KC * T); kc = r / T; t = r % T; }
+    else        { kc = i / (BN * T); const int r = i % (BN * T); n = r / T; t = r % T; }
+    const int nc = min(n0 + n, N - 1);
+    wsrc[e] = DGRAD ? (unsigned)((kc * N + nc) * T + t) : (unsigned)(nc * K * T + kc * T + t);
+    wdst[e] = n * WS + kc * T + t;
+    wkc[e] = kc;
+    wmask |= (n0 + n < N ? 1u : 0u) << e;
+  }
+  int spos[NP]; unsigned xsrc[NP]; bool xval[NP];
 #pragma unroll
   for (int e = 0; e < NP; ++e) {
     spos[e] = threadIdx.x + 256 * e;
-    soff[e] = -1; simg[e] = 0;
-    if (spos[e] < g.XS) pos_source(spos[e], p0, H, W, P, g, HALO, simg[e], soff[e]);
+    int soff = -1; long simg = 0;
+    if (spos[e] < XS) pos_source(spos[e], p0, H, W, P, g, HALO, simg, soff);
+    xval[e] = soff >= 0;
+    xsrc[e] = xval[e] ? (unsigned)simg * (unsigned)(K * HW) + (unsigned)soff : 0u;
   }
-  int poff[TM];
+  const int wstep = DGRAD ? N * T : T;               // weight-offset advance per input channel
+  int lbase[TM];                                     // lane part of the activation fragment address
 #pragma unroll
-  for (int mt = 0; mt < TM; ++mt) poff[mt] = pix_lds_off(mw + mt * 32 + l31, W, g, HALO);
+  for (int mt = 0; mt < TM; ++mt) lbase[mt] = half * XS + pix_lds_off(mw + mt * 32 + l31, W, g, HALO);
+  const int abase = (nw + l31) * WS + half * T;      // lane part of the weight fragment address
+
+  float wreg[NW], xreg[NP][KC];
+  auto fetch = [&](int k0) {
+    const float* __restrict__ wk = w + (long)k0 * wstep;                // wave-uniform bases
+    const float* __restrict__ xk = x + (long)k0 * HW;
+    if (k0 + KC <= K) {
+#pragma unroll
+      for (int e = 0; e < NW; ++e) wreg[e] = wk[wsrc[e]];
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        if (spos[p] < XS) {
+#pragma unroll
+          for (int kc = 0; kc < KC; ++kc) xreg[p][kc] = xk[xsrc[p] + (unsigned)(kc * HW)];
+        }
+    } else {                                         // ragged last chunk: clamp the channel, zero it at commit
+#pragma unroll
+      for (int e = 0; e < NW; ++e) wreg[e] = (k0 + wkc[e] < K) ? wk[wsrc[e]] : 0.f;
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        if (spos[p] < XS) {
+#pragma unroll
+          for (int kc = 0; kc < KC; ++kc) xreg[p][kc] = (k0 + kc < K) ? xk[xsrc[p] + (unsigned)(kc * HW)] : 0.f;
+        }
+    }
+  };
+  auto commit = [&](float* __restrict__ buf) {
+    float* __restrict__ Ws = buf;
+    float* __restrict__ Xs = buf + BN * WS;
+#pragma unroll
+    for (int e = 0; e < NW; ++e) Ws[wdst[e]] = ((wmask >> e) & 1u) ? wreg[e] : 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      if (spos[p] < XS) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) Xs[kc * XS + spos[p]] = xval[p] ? xreg[p][kc] : 0.f;
+      }
+  };
 
   f32x16 acc[TM];
 #pragma unroll
@@ -301,28 +369,31 @@ __global__ __launch_bounds__(256) void conv_mfma(const float* __restrict__ x, co
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-  Stager<T, DGRAD, BN, KC, NP> st;
-  st.fetch(w, x, 0, K, N, n0, HW, spos, soff, simg, g.XS);
-  for (int k0 = 0; k0 < K; k0 += KC) {
-    __syncthreads();                                  // previous chunk's fragment reads are done
-    st.commit(Ws, Xs, spos, g.XS);
-    __syncthreads();
-    if (k0 + KC < K) st.fetch(w, x, k0 + KC, K, N, n0, HW, spos, soff, simg, g.XS);   // in flight during the MFMAs
+  fetch(0);
+  commit(smem);
+  if (KC < K) fetch(KC);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < K; k0 += KC, cur ^= 1) {
+    if (k0 + KC < K) {
+      commit(smem + (cur ^ 1) * BUF);                 // chunk k0+KC (fetched one iteration ago) -> the idle buffer
+      if (k0 + 2 * KC < K) fetch(k0 + 2 * KC);        // in flight during the MFMAs below
+    }
+    const float* __restrict__ Ws = smem + cur * BUF;
+    const float* __restrict__ Xs = Ws + BN * WS;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const int toff = (T == 9) ? ((t / 3 - 1) * g.Wp + (t % 3 - 1)) : 0;
+      const int toff = (T == 9) ? ((t / 3 - 1) * Wp + (t % 3 - 1)) : 0;
       const int tw = DGRAD ? (T - 1 - t) : t;
 #pragma unroll
       for (int k2 = 0; k2 < KC / 2; ++k2) {
-        const int kc = 2 * k2 + half;
-        const float a = Ws[(nw + l31) * WS + kc * T + tw];
+        const float a = Ws[abase + 2 * k2 * T + tw];
 #pragma unroll
-        for (int mt = 0; mt < TM; ++mt) {
-          const float bv = Xs[kc * g.XS + poff[mt] + toff];
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[mt], 0, 0, 0);
-        }
+        for (int mt = 0; mt < TM; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Xs[lbase[mt] + 2 * k2 * XS + toff], acc[mt], 0, 0, 0);
       }
     }
+    __syncthreads();                                  // buffer `cur` is free again, buffer cur^1 is complete
   }
   // ---- epilogue: row n = (r&3) + 8*(r>>2) + 4*half, column = lane&31
 #pragma unroll
@@ -613,7 +684,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
 // ------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------
-static inline bool use_mfma(int K, int N, int H, int W, int PT) { return K >= 8 && N >= 8 && tile_ok(H, W, PT); }
+static inline bool use_mfma(int K, int N, int H, int W, int PT) { return N >= 8 && tile_ok(H, W, PT); }   // K < 8 (inc.conv1) rides the ragged-chunk path
 
 static int g_conv_path = 0;       // 0 auto, 1 force the 64x128 tile, 2 force the split-K small tile (tests)
 
@@ -642,15 +713,27 @@ static int launch_mfma(const float* x, const float* w, const float* bias, const 
       return 0;
     }
   }
+  // (a 64x256 tile was measured too: 222 VGPRs -> 1 wave/SIMD, 5-9 % slower than 64x128 at 2 waves/SIMD)
   const TileGeom g = make_geom(H, W, 128, T == 9 ? 1 : 0);
   if (g.XS > 512) return -1;                                            // staging plan holds 2 positions per thread
-  if (!use32) {
-    const size_t lds = sizeof(float) * (64 * (KC * T + 1) + (size_t)KC * g.XS);
-    hipLaunchKernelGGL((conv_mfma<T, DGRAD, 64, KC>), dim3((N + 63) / 64, ptiles), dim3(256), lds, s, x, w, bias, res, y, B, K, N, H, W, act, g);
-  } else {
-    const size_t lds = sizeof(float) * (32 * (KC * T + 1) + (size_t)KC * g.XS);
-    hipLaunchKernelGGL((conv_mfma<T, DGRAD, 32, KC>), dim3((N + 31) / 32, ptiles), dim3(256), lds, s, x, w, bias, res, y, B, K, N, H, W, act, g);
+  int geo = 0;
+  if (T == 1) geo = 5;
+  else if (H == W && (W == 32 || W == 16 || W == 8 || W == 4)) geo = W == 32 ? 1 : (W == 16 ? 2 : (W == 8 ? 3 : 4));
+  const size_t lds = 2 * sizeof(float) * ((use32 ? 32 : 64) * (KC * T + 1) + (size_t)KC * g.XS);   // two buffers
+  const dim3 grid(use32 ? (N + 31) / 32 : (N + 63) / 64, ptiles);
+#define AFD_CONV_LAUNCH(BN_, GEO_) hipLaunchKernelGGL((conv_mfma<T, DGRAD, BN_, KC, GEO_>), grid, dim3(256), lds, s, x, w, bias, res, y, B, K, N, H, W, act, g)
+#define AFD_CONV_GEO(BN_)                                             \
+  switch (geo) {                                                       \
+    case 1: if constexpr (T == 9) { AFD_CONV_LAUNCH(BN_, 1); } break;  \
+    case 2: if constexpr (T == 9) { AFD_CONV_LAUNCH(BN_, 2); } break;  \
+    case 3: if constexpr (T == 9) { AFD_CONV_LAUNCH(BN_, 3); } break;  \
+    case 4: if constexpr (T == 9) { AFD_CONV_LAUNCH(BN_, 4); } break;  \
+    case 5: if constexpr (T == 1) { AFD_CONV_LAUNCH(BN_, 5); } break;  \
+    default: AFD_CONV_LAUNCH(BN_, 0);                                  \
   }
+  if (!use32) { AFD_CONV_GEO(64) } else { AFD_CONV_GEO(32) }
+#undef AFD_CONV_GEO
+#undef AFD_CONV_LAUNCH
   return 0;
 }
 
