@@ -271,10 +271,37 @@ int afd_colsum(const float* in, float* out, int rows, int cols, int accumulate, 
   hipLaunchKernelGGL(colsum_k, dim3((cols + 31) / 32), dim3(256), 0, as_stream(st), in, out, rows, cols, (long)cols, accumulate);
   return check_launch("afd_colsum");
 }
+// (rows, 2, C) partials -> out_a[C] (+)= column sums of block 0, out_b[C] (+)= block 1; ONE launch
+__global__ __launch_bounds__(256) void colsum2_k(const float* __restrict__ in, float* __restrict__ oa, float* __restrict__ ob,
+                                                 int rows, int C, int accumulate) {
+  __shared__ float red[8][33];
+  const int j = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;     // j in [0, 2C)
+  float s0 = 0.f, s1 = 0.f;
+  if (j < 2 * C) {
+    int i = g;
+    for (; i + 8 < rows; i += 16) { s0 += in[(long)i * 2 * C + j]; s1 += in[(long)(i + 8) * 2 * C + j]; }
+    if (i < rows) s0 += in[(long)i * 2 * C + j];
+  }
+  red[g][threadIdx.x & 31] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && j < 2 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+    float* o = j < C ? oa + j : ob + (j - C);
+    *o = accumulate ? *o + t : t;
+  }
+}
+
 int afd_colsum_strided(const float* in, long row_stride, float* out, int rows, int cols, int accumulate, afd_stream_t st) {
   AFD_REQUIRE(in && out && rows > 0 && cols > 0 && row_stride >= cols, "afd_colsum_strided: bad argument");
   hipLaunchKernelGGL(colsum_k, dim3((cols + 31) / 32), dim3(256), 0, as_stream(st), in, out, rows, cols, row_stride, accumulate);
   return check_launch("afd_colsum_strided");
+}
+int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, int accumulate, afd_stream_t st) {
+  AFD_REQUIRE(in && out_a && out_b && rows > 0 && C > 0, "afd_colsum2: bad argument");
+  hipLaunchKernelGGL(colsum2_k, dim3((2 * C + 31) / 32), dim3(256), 0, as_stream(st), in, out_a, out_b, rows, C, accumulate);
+  return check_launch("afd_colsum2");
 }
 int afd_pos_encoding(const int64_t* t, const float* inv_freq, float* temb, int B, int half, afd_stream_t st) {
   AFD_REQUIRE(t && inv_freq && temb && B > 0 && half > 0, "afd_pos_encoding: bad argument");

@@ -259,16 +259,24 @@ __global__ __launch_bounds__(256) void filt_act_bwd_n3(const float* __restrict__
                                                        float* __restrict__ dv, long planes, int C,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ res,
-                                                       Taps3 u, Taps3 d) {
+                                                       float* __restrict__ part, Taps3 u, Taps3 d) {
   Lane<S> L(planes);
   const long b = L.plane / C; const int c = L.plane % C;
   const long base = L.plane * (long)S * S + L.col;
   float sc, sh;
   if (L.live) plane_affine(stats, gamma, beta, b, c, sc, sh); else { sc = 1.f; sh = 0.f; }
+  float mean = 0.f, rstd = 1.f;
+  if (part && L.live) { mean = stats[2 * b]; rstd = stats[2 * b + 1]; }
   float xv[S + 1], gv[S + 1];
+  float a1 = 0.f, a2 = 0.f;                         // GroupNorm-backward plane sums: sum dv*xhat, sum dv
+  float hx[S];                                      // xhat of the raw input (only needed for the partials)
 #pragma unroll
   for (int i = 0; i < S; ++i) {
-    xv[i] = L.live ? prologue(x, base + i * S, sc, sh, res) : 0.f;
+    const float h = L.live ? x[base + i * S] : 0.f;
+    float v = h * sc + sh;
+    if (res && L.live) v += res[base + i * S];
+    xv[i] = L.live ? v : 0.f;
+    hx[i] = (h - mean) * rstd;
     gv[i] = L.live ? dy[base + i * S] : 0.f;
   }
   xv[S] = 0.f; gv[S] = 0.f;
@@ -291,7 +299,13 @@ __global__ __launch_bounds__(256) void filt_act_bwd_n3(const float* __restrict__
                     + u.k[3] * dU01 + u.k[4] * dU00 + u.k[5] * dU01l
                     + u.k[6] * u11p + u.k[7] * u10p + u.k[8] * u11lp;
     if (L.live) dv[base + i * S] = out;
+    a1 += out * hx[i]; a2 += out;
     u10p = dU10; u11p = dU11; u11lp = dU11l; xr = xdr; gr = gdr;
+  }
+  if (part) {                                       // reduce over the S lanes that share the plane (fixed butterfly)
+#pragma unroll
+    for (int o = S / 2; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, kWave); a2 += __shfl_xor(a2, o, kWave); }
+    if (L.live && L.col == 0) { part[(2 * b) * C + c] = a1; part[(2 * b + 1) * C + c] = a2; }
   }
 }
 
@@ -442,17 +456,20 @@ int afd_filt_act_fwd(const float* x, float* y, int B, int C, int H, int W,
 
 int afd_filt_act_bwd(const float* x, const float* dy, float* dv, int B, int C, int H, int W,
                      const float* stats, const float* gamma, const float* beta, const float* res,
-                     const float* taps_up, const float* taps_down, int N, void* workspace, afd_stream_t stream) {
+                     const float* taps_up, const float* taps_down, int N, void* workspace, float* gn_partials,
+                     afd_stream_t stream) {
   if (int e = check_common("afd_filt_act_bwd", x, dy, B, C, H, W, taps_up, N)) return e;
   AFD_REQUIRE(dv && taps_down, "afd_filt_act_bwd: NULL pointer");
   hipStream_t s = as_stream(stream);
   const long planes = (long)B * C;
   if (N == 3 && fast_side(H, W)) {
     const Taps3 u = load_taps3(taps_up), d = load_taps3(taps_down);
-    AFD_DISPATCH_S(H, filt_act_bwd_n3, fast_grid(planes, H), dim3(256), 0, s, x, dy, dv, planes, C, stats, gamma, beta, res, u, d);
+    AFD_REQUIRE(!gn_partials || stats, "afd_filt_act_bwd: gn_partials needs stats");
+    AFD_DISPATCH_S(H, filt_act_bwd_n3, fast_grid(planes, H), dim3(256), 0, s, x, dy, dv, planes, C, stats, gamma, beta, res, gn_partials, u, d);
     return check_launch("afd_filt_act_bwd");
   }
   AFD_REQUIRE(workspace, "afd_filt_act_bwd: this shape (N=%d, %dx%d) needs a workspace", N, H, W);
+  AFD_REQUIRE(!gn_partials, "afd_filt_act_bwd: gn_partials are produced on the fused fast path only (workspace_bytes == 0)");
   const long e = planes * H * W;
   float* v = static_cast<float*>(workspace);
   float* U = v + e;

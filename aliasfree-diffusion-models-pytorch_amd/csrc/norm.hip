@@ -134,35 +134,36 @@ __global__ __launch_bounds__(256) void gn_bwd_plane(const float* __restrict__ x,
   }
 }
 
-// per sample: m1 = (1/n) sum_c gamma_c * A2[b,c] (= mean of gamma*dz), m2 = (1/n) sum_c gamma_c * A1[b,c]
-__global__ __launch_bounds__(256) void gn_bwd_sample(const float* __restrict__ part, const float* __restrict__ gamma,
-                                                     int C, float inv_n, float* __restrict__ m12) {
+// dx = rstd * (gamma*dz - m1 - xhat*m2), with m1 = mean_sample(gamma*dz), m2 = mean_sample(gamma*dz*xhat).
+// grid = (slices of the sample, B): every block first contracts the (2, C) partials of its sample with gamma
+// (C <= a few hundred values: cheaper than a separate launch), then applies its slice.
+__global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
+                                                    const float* __restrict__ stats, const float* __restrict__ part,
+                                                    int C, int HW, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const float* __restrict__ res, int act,
+                                                    float* __restrict__ dx) {
   __shared__ float red[16];
-  const long b = blockIdx.x;
+  const long b = blockIdx.y;
   float a = 0.f, c2 = 0.f;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float g = gamma[c];
     a += g * part[(2 * b + 1) * C + c];
     c2 += g * part[(2 * b) * C + c];
   }
-  a = block_sum(a, red);
-  c2 = block_sum(c2, red);
-  if (threadIdx.x == 0) { m12[2 * b] = a * inv_n; m12[2 * b + 1] = c2 * inv_n; }
-}
-
-// dx = rstd * (gamma*dz - m1 - xhat*m2)
-__global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
-                                                    const float* __restrict__ stats, const float* __restrict__ m12,
-                                                    int C, int HW, long total, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, const float* __restrict__ res, int act,
-                                                    float* __restrict__ dx) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long pl = i / HW; const long b = pl / C; const int c = pl % C;
-    const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+  const float inv_n = 1.0f / (float)((long)C * HW);
+  const float m1 = block_sum(a, red) * inv_n;
+  const float m2 = block_sum(c2, red) * inv_n;
+  const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+  const long n = (long)C * HW;
+  const long per = (n + gridDim.x - 1) / gridDim.x;
+  const long lo = blockIdx.x * per, hi = min(n, lo + per);
+  for (long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const int c = (int)(i / HW);
+    const long gi = b * n + i;
     const float g = gamma[c];
-    const float xh = (x[i] - mean) * rstd;
-    const float dz = gn_dz(xh, dy[i], g, beta[c], res ? res[i] : 0.f, act);
-    dx[i] = rstd * (g * dz - m12[2 * b] - xh * m12[2 * b + 1]);
+    const float xh = (x[gi] - mean) * rstd;
+    const float dz = gn_dz(xh, dy[gi], g, beta[c], res ? res[gi] : 0.f, act);
+    dx[gi] = rstd * (g * dz - m1 - xh * m2);
   }
 }
 
@@ -314,16 +315,20 @@ int afd_groupnorm1_fwd(const float* x, float* y, float* stats_out, int B, int C,
 
 int afd_groupnorm1_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
                        const float* gamma, const float* beta, const float* res, int act,
-                       float* dx, float* dres, float* part, float* demb, afd_stream_t st) {
+                       float* dx, float* dres, float* part, float* demb, int have_partials, afd_stream_t st) {
   AFD_REQUIRE(x && dy && stats && gamma && beta && dx && part && B > 0 && C > 0 && HW > 0, "afd_groupnorm1_bwd: bad argument");
   AFD_REQUIRE(act == 0 || act == 1, "afd_groupnorm1_bwd: act must be 0 or 1");
+  AFD_REQUIRE(!have_partials || (!dres && !demb && act == 0 && !res), "afd_groupnorm1_bwd: have_partials only for the plain form");
   hipStream_t s = as_stream(st);
-  const long planes = (long)B * C, total = planes * HW;
-  hipLaunchKernelGGL(gn_bwd_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, x, dy, stats, C, HW, planes, gamma, beta, res, act, dres, part, demb);
-  // per-sample contractions go behind the partials: `part` is (B*C*2 + B*2) floats (see afd.h)
-  float* m12 = part + 2 * planes;
-  hipLaunchKernelGGL(gn_bwd_sample, dim3(B), dim3(256), 0, s, part, gamma, C, 1.0f / (float)((long)C * HW), m12);
-  hipLaunchKernelGGL(gn_bwd_apply, dim3(gs_grid(total)), dim3(256), 0, s, x, dy, stats, m12, C, HW, total, gamma, beta, res, act, dx);
+  const long planes = (long)B * C;
+  if (!have_partials)
+    hipLaunchKernelGGL(gn_bwd_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, x, dy, stats, C, HW, planes, gamma, beta, res, act, dres, part, demb);
+  const long n = (long)C * HW;
+  int slices = (int)((n + 4095) / 4096);               // ~16 elements per thread
+  if (slices < 1) slices = 1;
+  if (slices > 64) slices = 64;
+  AFD_REQUIRE(B <= 65535, "afd_groupnorm1_bwd: batch too large for the grid");
+  hipLaunchKernelGGL(gn_bwd_apply, dim3(slices, B), dim3(256), 0, s, x, dy, stats, part, C, HW, gamma, beta, res, act, dx);
   return check_launch("afd_groupnorm1_bwd");
 }
 

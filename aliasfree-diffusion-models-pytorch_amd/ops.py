@@ -123,7 +123,7 @@ class FiltAct(torch.autograd.Function):
         dx = torch.empty_like(x)
         ws = _act_ws(B, C, H, W, ctx.tu.N, 1, x.device)
         lib().afd_filt_act_bwd(_p(x), _p(dy), _p(dx), B, C, H, W, None, None, None, None,
-                               ctx.tu.ptr, ctx.td.ptr, ctx.tu.N, _p(ws), _stream())
+                               ctx.tu.ptr, ctx.td.ptr, ctx.tu.N, _p(ws), None, _stream())
         return dx, None, None
 
 
@@ -164,8 +164,7 @@ def _gn_param_grads(part, B, C, gamma=None, beta=None):
     if gamma is not None and _direct(gamma, beta):
         L = lib()
         # rows of `part` are 2C wide: column block [0,C) -> dgamma, [C,2C) -> dbeta; accumulate in place
-        L.afd_colsum_strided(_p(part), 2 * C, _p(gamma.grad), B, C, 1, _stream())
-        L.afd_colsum_strided(part.data_ptr() + 4 * C, 2 * C, _p(beta.grad), B, C, 1, _stream())
+        L.afd_colsum2(_p(part), _p(gamma.grad), _p(beta.grad), B, C, 1, _stream())
         return None, None
     out = torch.empty(2, C, device=part.device, dtype=torch.float32)
     lib().afd_colsum(_p(part), _p(out), B, 2 * C, 0, _stream())
@@ -197,10 +196,10 @@ class GroupNorm1(torch.autograd.Function):
         dres = None
         if res is not None:
             dres = dy if ctx.act == 0 else torch.empty_like(x)      # act == 0: d(res) is dy itself
-        part = torch.empty(B * C * 2 + B * 2, device=x.device, dtype=torch.float32)
+        part = torch.empty(B * C * 2, device=x.device, dtype=torch.float32)
         demb = torch.empty(B, C, device=x.device, dtype=torch.float32) if ctx.has_emb else None
         lib().afd_groupnorm1_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(beta), _p(res), ctx.act,
-                                 _p(dx), _p(dres) if (res is not None and ctx.act == 1) else None, _p(part), _p(demb), _stream())
+                                 _p(dx), _p(dres) if (res is not None and ctx.act == 1) else None, _p(part), _p(demb), 0, _stream())
         dgamma, dbeta = _gn_param_grads(part, B, C, gamma, beta)
         return dx, dgamma, dbeta, dres, demb, None
 
@@ -236,12 +235,13 @@ class GroupNormFiltAct(torch.autograd.Function):
         L = lib()
         dv = torch.empty_like(x)
         ws = _act_ws(B, C, H, W, ctx.tu.N, 1, x.device)
+        part = torch.empty(B * C * 2, device=x.device, dtype=torch.float32)
+        fused = ws is None                 # fast path: the filtered-GELU backward also emits the GroupNorm plane sums
         L.afd_filt_act_bwd(_p(x), _p(dy), _p(dv), B, C, H, W, _p(stats), _p(gamma), _p(beta), _p(res),
-                           ctx.tu.ptr, ctx.td.ptr, ctx.tu.N, _p(ws), _stream())
+                           ctx.tu.ptr, ctx.td.ptr, ctx.tu.N, _p(ws), _p(part) if fused else None, _stream())
         dx = torch.empty_like(x)
-        part = torch.empty(B * C * 2 + B * 2, device=x.device, dtype=torch.float32)
         L.afd_groupnorm1_bwd(_p(x), _p(dv), _p(stats), B, C, H * W, _p(gamma), _p(beta), None, 0,
-                             _p(dx), None, _p(part), None, _stream())
+                             _p(dx), None, _p(part), None, 1 if fused else 0, _stream())
         dgamma, dbeta = _gn_param_grads(part, B, C, gamma, beta)
         return dx, dgamma, dbeta, (dv if res is not None else None), None, None
 

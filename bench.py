@@ -106,7 +106,7 @@ def kernel_table(dev, B):
             st = torch.zeros(B, 2, device=dev); st[:, 1] = 1
             g = torch.ones(C, device=dev); be = torch.zeros(C, device=dev)
             tf = ev_time(lambda: L.afd_filt_act_fwd(x.data_ptr(), y.data_ptr(), B, C, S, S, st.data_ptr(), g.data_ptr(), be.data_ptr(), None, tk.ptr, tk.ptr, 3, None, s))
-            tb = ev_time(lambda: L.afd_filt_act_bwd(x.data_ptr(), y.data_ptr(), dv.data_ptr(), B, C, S, S, st.data_ptr(), g.data_ptr(), be.data_ptr(), None, tk.ptr, tk.ptr, 3, None, s))
+            tb = ev_time(lambda: L.afd_filt_act_bwd(x.data_ptr(), y.data_ptr(), dv.data_ptr(), B, C, S, S, st.data_ptr(), g.data_ptr(), be.data_ptr(), None, tk.ptr, tk.ptr, 3, None, None, s))
             tg = ev_time(lambda: L.afd_groupnorm1_fwd(x.data_ptr(), None, st.data_ptr(), B, C, S * S, 1e-5, None, None, None, 0, None, s))
             seen[(C, S)] = (tf, tb, tg)
             del x, y, dv

@@ -62,7 +62,9 @@ int afd_filt_down2_bwd(const float* dy, float* dx, int B, int C, int H, int W, l
  * stats: float[B*2] = {mean, rstd} per sample, or NULL (then gamma/beta are ignored).
  * workspace: only read when the shape is off the fused fast path (N != 3 or a non-square /
  * non-power-of-two plane); size from afd_filt_act_workspace_bytes (0 on the fast path).
- * bwd writes dv = dL/dv (same shape as x); the caller chains dv into GroupNorm-backward / the residual. */
+ * bwd writes dv = dL/dv (same shape as x); the caller chains dv into GroupNorm-backward / the residual.
+ * gn_partials (or NULL; needs stats; fused fast path only): the kernel also emits GroupNorm-backward's
+ * per-plane sums of dv, layout (B,2,C) -- pass them to afd_groupnorm1_bwd with have_partials = 1. */
 size_t afd_filt_act_workspace_bytes(int B, int C, int H, int W, int N, int backward);
 int afd_filt_act_fwd(const float* x, float* y, int B, int C, int H, int W,
                      const float* stats, const float* gamma, const float* beta, const float* res,
@@ -71,7 +73,7 @@ int afd_filt_act_fwd(const float* x, float* y, int B, int C, int H, int W,
 int afd_filt_act_bwd(const float* x, const float* dy, float* dv, int B, int C, int H, int W,
                      const float* stats, const float* gamma, const float* beta, const float* res,
                      const float* taps_up, const float* taps_down, int N,
-                     void* workspace, afd_stream_t stream);
+                     void* workspace, float* gn_partials, afd_stream_t stream);
 
 /* ---- F6: nn.GroupNorm(1, C), eps, affine ---------------------------- ddpm_utils.py:85,88,113,116
  * fwd: stats_out[b] = {mean, rstd}; if y != NULL:
@@ -81,19 +83,20 @@ int afd_filt_act_bwd(const float* x, const float* dy, float* dv, int B, int C, i
  *   emb  (B,C) or NULL     : time-embedding add of Down/Up (:218-219, :244-245).
  * bwd: given dy (= dL/dy) recomputes the chain; writes dx, dres (may be NULL), and per-sample
  *   partials laid out (B, 2, C): [b][0][c] = sum dz*xhat (-> dgamma), [b][1][c] = sum dz (-> dbeta), which
- *   afd_colsum reduces over b into a (2, C) row pair.  The partial buffer must hold B*C*2 + B*2 floats (the
- *   tail is scratch).  demb = sum_hw dy is (B,C). */
+ *   afd_colsum reduces over b into a (2, C) row pair.  The partial buffer holds B*C*2 floats.  demb = sum_hw dy is (B,C). */
 int afd_groupnorm1_fwd(const float* x, float* y, float* stats_out, int B, int C, int HW, float eps,
                        const float* gamma, const float* beta, const float* res, int act, const float* emb,
                        afd_stream_t stream);
 int afd_groupnorm1_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
                        const float* gamma, const float* beta, const float* res, int act,
-                       float* dx, float* dres, float* dgamma_dbeta_partial /* B*C*2 + B*2 floats */, float* demb /* (B,C) or NULL */,
-                       afd_stream_t stream);
+                       float* dx, float* dres, float* dgamma_dbeta_partial /* B*C*2 floats, (B,2,C) */, float* demb /* (B,C) or NULL */,
+                       int have_partials /* 1: the partials were already produced by afd_filt_act_bwd */, afd_stream_t stream);
 /* out[j] (+)= sum_i in[i*cols + j], i < rows (deterministic tree; accumulate != 0 adds into out) */
 int afd_colsum(const float* in, float* out, int rows, int cols, int accumulate, afd_stream_t stream);
 /* same with an explicit row stride (elements): sums a column block of a wider matrix */
 int afd_colsum_strided(const float* in, long row_stride, float* out, int rows, int cols, int accumulate, afd_stream_t stream);
+/* (rows,2,C) partials -> out_a[C] (+)= sum over rows of block 0, out_b[C] (+)= block 1, in one launch */
+int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, int accumulate, afd_stream_t stream);
 
 /* ---- F5/F10: convolution as implicit GEMM (3x3 pad 1, or 1x1) --------- ddpm_utils.py:84,87,112,115;
  *      nn.Linear / MHA projections on NCHW tokens (ddpm_utils.py:59-66,71,73); outc (ddpm_models.py:84)
