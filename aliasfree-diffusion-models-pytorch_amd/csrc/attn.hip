@@ -260,30 +260,55 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
 }  // namespace afd
 using namespace afd;
 
-// rows per lane by head dim (register budget) -- fwd/dq: 4,4,4,2,2,1 ; dkv (4 vectors per row): 4,4,2,2,1,1
-#define AFD_ATTN_CASE(D_, R_, KERNEL, ...)                                                          \
-  case D_: {                                                                                        \
-    const int rows = (L + (R_) - 1) / (R_);                                                         \
-    const dim3 block(rows <= 64 ? 64 : (rows <= 128 ? 128 : 256));                                  \
-    const dim3 grid((L + block.x * (R_) - 1) / (block.x * (R_)), heads, B);                         \
-    hipLaunchKernelGGL((KERNEL<D_, R_>), grid, block, 0, s, __VA_ARGS__);                           \
-  } break;
+template <int R> static inline void attn_geometry(int B, int heads, int L, dim3& grid, dim3& block) {
+  const int rows = (L + R - 1) / R;
+  block = dim3(rows <= 64 ? 64 : (rows <= 128 ? 128 : 256));
+  grid = dim3((L + block.x * R - 1) / (block.x * R), heads, B);
+}
+template <int D, int R> static void launch_fwd(const float* qkv, float* o, float* lse, int B, int heads, int L, float sc, hipStream_t s) {
+  dim3 grid, block; attn_geometry<R>(B, heads, L, grid, block);
+  hipLaunchKernelGGL((attn_fwd_k<D, R>), grid, block, 0, s, qkv, o, lse, heads, L, sc);
+}
+template <int D, int R> static void launch_dq(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
+                                              float* delta, int B, int heads, int L, float sc, hipStream_t s) {
+  dim3 grid, block; attn_geometry<R>(B, heads, L, grid, block);
+  hipLaunchKernelGGL((attn_bwd_dq_k<D, R>), grid, block, 0, s, qkv, o, d_o, lse, dqkv, delta, heads, L, sc);
+}
+template <int D, int R> static void launch_dkv(const float* qkv, const float* d_o, const float* lse, const float* delta, float* dqkv,
+                                               int B, int heads, int L, float sc, hipStream_t s) {
+  dim3 grid, block; attn_geometry<R>(B, heads, L, grid, block);
+  hipLaunchKernelGGL((attn_bwd_dkv_k<D, R>), grid, block, 0, s, qkv, d_o, lse, delta, dqkv, heads, L, sc);
+}
+
+static int g_attn_rows = 0;      // tuning hook: 0 = default rows per lane, else force R in {1,2,4} for d = 8
 
 extern "C" {
+
+int afd_debug_attn_rows(int r) {
+  AFD_REQUIRE(r == 0 || r == 1 || r == 2 || r == 4, "afd_debug_attn_rows: r must be 0, 1, 2 or 4");
+  g_attn_rows = r;
+  return AFD_OK;
+}
 
 int afd_attn_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d, int L, afd_stream_t st) {
   AFD_REQUIRE(qkv && o && lse && B > 0 && heads > 0 && L > 0, "afd_attn_fwd: bad argument");
   AFD_REQUIRE(d == 2 || d == 4 || d == 8 || d == 16 || d == 32 || d == 64, "afd_attn_fwd: head dim %d not in {2,4,8,16,32,64}", d);
   AFD_REQUIRE(B <= 65535 && heads <= 65535, "afd_attn_fwd: grid too large");
   hipStream_t s = as_stream(st);
-  const float scale = 1.0f / sqrtf((float)d);
+  const float sc = 1.0f / sqrtf((float)d);
+  // rows per lane by head dim (register budget): 4,4,4,2,2,1
   switch (d) {
-    AFD_ATTN_CASE(2, 4, attn_fwd_k, qkv, o, lse, heads, L, scale)
-    AFD_ATTN_CASE(4, 4, attn_fwd_k, qkv, o, lse, heads, L, scale)
-    AFD_ATTN_CASE(8, 4, attn_fwd_k, qkv, o, lse, heads, L, scale)
-    AFD_ATTN_CASE(16, 2, attn_fwd_k, qkv, o, lse, heads, L, scale)
-    AFD_ATTN_CASE(32, 2, attn_fwd_k, qkv, o, lse, heads, L, scale)
-    AFD_ATTN_CASE(64, 1, attn_fwd_k, qkv, o, lse, heads, L, scale)
+    case 2:  launch_fwd<2, 4>(qkv, o, lse, B, heads, L, sc, s); break;
+    case 4:  launch_fwd<4, 4>(qkv, o, lse, B, heads, L, sc, s); break;
+    case 8:
+      // measured (tools/attn_bench.py, B=256): R=2 wins at L=1024, R=1 at L<=256 (4x the waves)
+      if (g_attn_rows == 1 || (g_attn_rows == 0 && L < 1024)) launch_fwd<8, 1>(qkv, o, lse, B, heads, L, sc, s);
+      else if (g_attn_rows == 4) launch_fwd<8, 4>(qkv, o, lse, B, heads, L, sc, s);
+      else launch_fwd<8, 2>(qkv, o, lse, B, heads, L, sc, s);
+      break;
+    case 16: launch_fwd<16, 2>(qkv, o, lse, B, heads, L, sc, s); break;
+    case 32: launch_fwd<32, 2>(qkv, o, lse, B, heads, L, sc, s); break;
+    default: launch_fwd<64, 1>(qkv, o, lse, B, heads, L, sc, s); break;
   }
   return check_launch("afd_attn_fwd");
 }
@@ -294,22 +319,30 @@ int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float
   AFD_REQUIRE(d == 2 || d == 4 || d == 8 || d == 16 || d == 32 || d == 64, "afd_attn_bwd: head dim %d not in {2,4,8,16,32,64}", d);
   AFD_REQUIRE(B <= 65535 && heads <= 65535, "afd_attn_bwd: grid too large");
   hipStream_t s = as_stream(st);
-  const float scale = 1.0f / sqrtf((float)d);
-  switch (d) {
-    AFD_ATTN_CASE(2, 4, attn_bwd_dq_k, qkv, o, d_o, lse, dqkv, delta_ws, heads, L, scale)
-    AFD_ATTN_CASE(4, 4, attn_bwd_dq_k, qkv, o, d_o, lse, dqkv, delta_ws, heads, L, scale)
-    AFD_ATTN_CASE(8, 4, attn_bwd_dq_k, qkv, o, d_o, lse, dqkv, delta_ws, heads, L, scale)
-    AFD_ATTN_CASE(16, 2, attn_bwd_dq_k, qkv, o, d_o, lse, dqkv, delta_ws, heads, L, scale)
-    AFD_ATTN_CASE(32, 2, attn_bwd_dq_k, qkv, o, d_o, lse, dqkv, delta_ws, heads, L, scale)
-    AFD_ATTN_CASE(64, 1, attn_bwd_dq_k, qkv, o, d_o, lse, dqkv, delta_ws, heads, L, scale)
+  const float sc = 1.0f / sqrtf((float)d);
+  switch (d) {      // dQ pass: rows per lane 4,4,4,2,2,1
+    case 2:  launch_dq<2, 4>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); break;
+    case 4:  launch_dq<4, 4>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); break;
+    case 8:
+      if (g_attn_rows == 1 || (g_attn_rows == 0 && L < 1024)) launch_dq<8, 1>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s);
+      else if (g_attn_rows == 4) launch_dq<8, 4>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s);
+      else launch_dq<8, 2>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s);
+      break;
+    case 16: launch_dq<16, 2>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); break;
+    case 32: launch_dq<32, 2>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); break;
+    default: launch_dq<64, 1>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); break;
   }
-  switch (d) {
-    AFD_ATTN_CASE(2, 4, attn_bwd_dkv_k, qkv, d_o, lse, delta_ws, dqkv, heads, L, scale)
-    AFD_ATTN_CASE(4, 4, attn_bwd_dkv_k, qkv, d_o, lse, delta_ws, dqkv, heads, L, scale)
-    AFD_ATTN_CASE(8, 2, attn_bwd_dkv_k, qkv, d_o, lse, delta_ws, dqkv, heads, L, scale)
-    AFD_ATTN_CASE(16, 2, attn_bwd_dkv_k, qkv, d_o, lse, delta_ws, dqkv, heads, L, scale)
-    AFD_ATTN_CASE(32, 1, attn_bwd_dkv_k, qkv, d_o, lse, delta_ws, dqkv, heads, L, scale)
-    AFD_ATTN_CASE(64, 1, attn_bwd_dkv_k, qkv, d_o, lse, delta_ws, dqkv, heads, L, scale)
+  switch (d) {      // dK/dV pass (4 vectors per row): 4,4,2,2,1,1
+    case 2:  launch_dkv<2, 4>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s); break;
+    case 4:  launch_dkv<4, 4>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s); break;
+    case 8:
+      if (g_attn_rows == 1 || (g_attn_rows == 0 && L < 1024)) launch_dkv<8, 1>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s);
+      else if (g_attn_rows == 4) launch_dkv<8, 4>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s);
+      else launch_dkv<8, 2>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s);
+      break;
+    case 16: launch_dkv<16, 2>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s); break;
+    case 32: launch_dkv<32, 1>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s); break;
+    default: launch_dkv<64, 1>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s); break;
   }
   return check_launch("afd_attn_bwd");
 }

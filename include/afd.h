@@ -129,6 +129,8 @@ int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int
  * ddpm_utils.py:71 (nn.MultiheadAttention, batch_first, 4 heads).  qkv (B,3C,L): channel
  * n = {0:q,1:k,2:v}*C + head*d + j, token index contiguous (the NCHW image of in_proj's output).
  * o (B,C,L); lse (B,heads,L) saved for backward.  Never materialises the L x L scores. */
+/* tuning hook: force R rows per lane (1, 2, 4) for head dim 8; 0 = default */
+int afd_debug_attn_rows(int rows);
 int afd_attn_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d, int L, afd_stream_t stream);
 int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                  float* delta_workspace /* (B,heads,L) floats */, int B, int heads, int d, int L, afd_stream_t stream);
