@@ -35,7 +35,8 @@ __global__ void noise_images_k(const float* __restrict__ x, const float* __restr
 // x' = 1/sqrt(a) * (x - ((1-a)/sqrt(1-ah)) * eps) + sqrt(b) * noise
 __global__ void denoise_step_k(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
                                const float* __restrict__ alpha, const float* __restrict__ alpha_hat, const float* __restrict__ beta,
-                               int step, float* __restrict__ out, long n) {
+                               int step_arg, const int64_t* __restrict__ step_dev, float* __restrict__ out, long n) {
+  const int step = step_dev ? (int)step_dev[0] : step_arg;     // device-resident index: a captured graph replays for every i
   const float a = alpha[step], ah = alpha_hat[step], bt = beta[step];
   const float c1 = 1.0f / sqrtf(a);
   const float c2 = (1.0f - a) / sqrtf(1.0f - ah);
@@ -119,8 +120,14 @@ int afd_noise_images(const float* x, const float* eps, const int64_t* t, const f
 int afd_denoise_step(const float* x, const float* eps_pred, const float* noise, const float* alpha, const float* alpha_hat,
                      const float* beta, int i, float* x_out, long n, afd_stream_t st) {
   AFD_REQUIRE(x && eps_pred && alpha && alpha_hat && beta && x_out && n > 0 && i >= 0, "afd_denoise_step: bad argument");
-  hipLaunchKernelGGL(denoise_step_k, dim3(gs_grid(n)), dim3(256), 0, as_stream(st), x, eps_pred, noise, alpha, alpha_hat, beta, i, x_out, n);
+  hipLaunchKernelGGL(denoise_step_k, dim3(gs_grid(n)), dim3(256), 0, as_stream(st), x, eps_pred, noise, alpha, alpha_hat, beta, i, (const int64_t*)nullptr, x_out, n);
   return check_launch("afd_denoise_step");
+}
+int afd_denoise_step_dev(const float* x, const float* eps_pred, const float* noise, const float* alpha, const float* alpha_hat,
+                         const float* beta, const int64_t* t_dev, float* x_out, long n, afd_stream_t st) {
+  AFD_REQUIRE(x && eps_pred && alpha && alpha_hat && beta && t_dev && x_out && n > 0, "afd_denoise_step_dev: bad argument");
+  hipLaunchKernelGGL(denoise_step_k, dim3(gs_grid(n)), dim3(256), 0, as_stream(st), x, eps_pred, noise, alpha, alpha_hat, beta, 0, t_dev, x_out, n);
+  return check_launch("afd_denoise_step_dev");
 }
 int afd_quantize_u8(const float* x, uint8_t* out, long n, afd_stream_t st) {
   AFD_REQUIRE(x && out && n > 0, "afd_quantize_u8: bad argument");

@@ -60,16 +60,27 @@ class Diffusion:
             return torch.randn(x.shape).to(x.device)
         return torch.randn_like(x)
 
-    def _loop(self, model, n, image_channels, theta=None, noise_source="reference", keep_float=False):
+    def _loop(self, model, n, image_channels, theta=None, noise_source="reference", graph=None):
         """Shared body of sample / revert.  noise_source: 'reference' (x_T from the CPU generator,
         per-step noise from the device generator -- what the reference does on a GPU), 'cpu'
-        (everything from the CPU generator: reproduces the reference's CPU run), 'device'."""
+        (everything from the CPU generator: reproduces the reference's CPU run), 'device'.
+        graph: capture ONE denoise step (UNet forward + device noise + update) into a hipGraph and replay
+        it for i = T-1 .. 2 (the step index lives in device memory).  Off by default: measured on MI355X the
+        loop is bound by the ~330 dependent kernel boundaries per step on the device (2.18 ms/step at n=6
+        with or without replay), not by host launches."""
         theta_step = None if theta is None else theta / self.noise_steps
+        if graph is None:
+            graph = False
         model.eval()
         snaps = []
         with torch.no_grad():
             x = self._initial_noise(n, image_channels, noise_source)
-            for i in reversed(range(1, self.noise_steps)):
+            if graph and theta is None and noise_source != "cpu":
+                x = self._graph_steps(model, x, snaps)
+                first_eager = 1
+            else:
+                first_eager = self.noise_steps - 1
+            for i in reversed(range(1, first_eager + 1)):
                 t = self._t_full(n, i, x.device)
                 eps = model(x, t)
                 noise = self._step_noise(x, noise_source) if i > 1 else None
@@ -82,20 +93,48 @@ class Diffusion:
         snaps.append(x)
         return x, snaps
 
-    def sample(self, model, n, image_channels, theta=None, noise_source="reference", return_float=False):
+    def _graph_steps(self, model, x, snaps):
+        """Steps i = T-1 .. 2 by replaying one captured step; returns x after step 2."""
+        n = x.shape[0]
+        t_dev = torch.full((n,), self.noise_steps - 1, device=x.device, dtype=torch.long)
+        xs = x.clone()
+
+        def one_step():
+            eps = model(xs, t_dev)
+            noise = torch.randn_like(xs)
+            ops.denoise_step_dev(xs, eps, noise, self.alpha, self.alpha_hat, self.beta, t_dev, xs)   # in place (elementwise)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        keep = xs.clone()
+        with torch.cuda.stream(side):
+            one_step()                                   # warm-up (allocator, lazy init); its effect is undone below
+        torch.cuda.current_stream().wait_stream(side)
+        xs.copy_(keep)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            one_step()
+        for i in reversed(range(2, self.noise_steps)):
+            t_dev.fill_(i)
+            g.replay()
+            if i % 100 == 0:
+                snaps.append(xs.clone())
+        return xs.clone()
+
+    def sample(self, model, n, image_channels, theta=None, noise_source="reference", return_float=False, graph=None):
         logging.info(f"Sampling {n} new images....")
         if theta is not None:
             logging.info(f"Theta {theta} provided. Rotation will be applied.")
-        x, snaps = self._loop(model, n, image_channels, theta, noise_source)
+        x, snaps = self._loop(model, n, image_channels, theta, noise_source, graph)
         xq = ops.quantize_u8(x)
         rq = ops.quantize_u8(torch.cat(snaps))
         if return_float:
             return xq, rq, x
         return xq, rq
 
-    def revert(self, model, n, image_channels, noise_source="reference"):
+    def revert(self, model, n, image_channels, noise_source="reference", graph=None):
         logging.info(f"Sampling {n} new images....")
-        _, snaps = self._loop(model, n, image_channels, None, noise_source)
+        _, snaps = self._loop(model, n, image_channels, None, noise_source, graph)
         return ops.quantize_u8(torch.cat(snaps))
 
     # under development in the reference (:388-419); kept as a host-driven loop over the HIP step

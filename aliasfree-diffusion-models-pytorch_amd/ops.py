@@ -523,6 +523,14 @@ def denoise_step(x, eps_pred, noise, alpha, alpha_hat, beta, i, out=None):
     return out
 
 
+def denoise_step_dev(x, eps_pred, noise, alpha, alpha_hat, beta, t_dev, out):
+    """Denoise update whose step index is t_dev[0] on the device (graph-replayable)."""
+    _chk(x, eps_pred, noise)
+    lib().afd_denoise_step_dev(_p(x), _p(eps_pred), _p(noise), _p(alpha), _p(alpha_hat), _p(beta), _p(t_dev), _p(out),
+                               x.numel(), _stream())
+    return out
+
+
 def quantize_u8(x):
     _chk(x)
     x = _c(x)

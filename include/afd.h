@@ -167,6 +167,10 @@ int afd_noise_images(const float* x, const float* eps, const int64_t* t, const f
 int afd_denoise_step(const float* x, const float* eps_pred, const float* noise /* NULL => zeros (i == 1) */,
                      const float* alpha, const float* alpha_hat, const float* beta, int i,
                      float* x_out, long n, afd_stream_t stream);
+/* same update with the step index read from device memory (t_dev[0]): the form a captured hipGraph replays */
+int afd_denoise_step_dev(const float* x, const float* eps_pred, const float* noise,
+                         const float* alpha, const float* alpha_hat, const float* beta, const int64_t* t_dev,
+                         float* x_out, long n, afd_stream_t stream);
 int afd_quantize_u8(const float* x, uint8_t* out, long n, afd_stream_t stream);
 
 /* ---- F15: loss + optimiser ------------------------------------------- ddpm_utils.py:489-490,503-507
