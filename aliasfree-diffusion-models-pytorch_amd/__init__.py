@@ -14,4 +14,7 @@ from .diffusion import Diffusion  # noqa: F401
 from .training import (argument, set_seed, setup_logging, train, TrainStep, FusedAdamW, FlatParams,  # noqa: F401
                        GradAllReduce)
 
+from .tasks import ddpm_run, rotation_results, shift_results  # noqa: F401
+from .data import get_data, get_data_MNIST, save_gen_images, make_collage  # noqa: F401
+
 __version__ = "0.1.0"

@@ -166,23 +166,31 @@ __global__ void silu_linear_fwd_k(const float* __restrict__ temb, const float* _
   s = wave_sum(s);
   if (lane == 0) out[wv] = s + (bias ? bias[n] : 0.f);
 }
-// dw[n,k] = sum_b dout[b,n] silu(temb[b,k]);  one thread per (n,k)
-__global__ void silu_linear_dw_k(const float* __restrict__ temb, const float* __restrict__ dout, float* __restrict__ dw,
-                                 int B, int K, int N, int accumulate) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)N * K) return;
-  const int n = i / K, k = i % K;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 4 <= B; b += 4) {
-    s0 += dout[(long)b * N + n] * silu(temb[(long)b * K + k]);
-    s1 += dout[(long)(b + 1) * N + n] * silu(temb[(long)(b + 1) * K + k]);
-    s2 += dout[(long)(b + 2) * N + n] * silu(temb[(long)(b + 2) * K + k]);
-    s3 += dout[(long)(b + 3) * N + n] * silu(temb[(long)(b + 3) * K + k]);
+// dw[n,k] = sum_b dout[b,n] silu(temb[b,k]).  Block = one output row n x 32 columns k x 8 batch groups;
+// the 8 partial sums meet in LDS (fixed order).
+__global__ __launch_bounds__(256) void silu_linear_dw_k(const float* __restrict__ temb, const float* __restrict__ dout, float* __restrict__ dw,
+                                                        int B, int K, int N, int accumulate) {
+  __shared__ float red[8][33];
+  const int n = blockIdx.y;
+  const int k = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  float s0 = 0.f, s1 = 0.f;
+  if (k < K) {
+    int b = g;
+    for (; b + 8 < B; b += 16) {
+      s0 += dout[(long)b * N + n] * silu(temb[(long)b * K + k]);
+      s1 += dout[(long)(b + 8) * N + n] * silu(temb[(long)(b + 8) * K + k]);
+    }
+    if (b < B) s0 += dout[(long)b * N + n] * silu(temb[(long)b * K + k]);
   }
-  for (; b < B; ++b) s0 += dout[(long)b * N + n] * silu(temb[(long)b * K + k]);
-  const float s = (s0 + s1) + (s2 + s3);
-  dw[i] = accumulate ? dw[i] + s : s;
+  red[g][threadIdx.x & 31] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && k < K) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += red[j][threadIdx.x & 31];
+    float* o = dw + (long)n * K + k;
+    *o = accumulate ? *o + t : t;
+  }
 }
 __global__ void silu_linear_db_k(const float* __restrict__ dout, float* __restrict__ db, int B, int N, int accumulate) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,7 +326,7 @@ int afd_silu_linear_bwd(const float* temb, const float* w, const float* dout, fl
                         int B, int K, int N, int accumulate, afd_stream_t st) {
   AFD_REQUIRE(temb && w && dout && dw && B > 0 && K > 0 && N > 0, "afd_silu_linear_bwd: bad argument");
   hipStream_t s = as_stream(st);
-  hipLaunchKernelGGL(silu_linear_dw_k, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, s, temb, dout, dw, B, K, N, accumulate);
+  hipLaunchKernelGGL(silu_linear_dw_k, dim3((K + 31) / 32, N), dim3(256), 0, s, temb, dout, dw, B, K, N, accumulate);
   if (dbias) hipLaunchKernelGGL(silu_linear_db_k, dim3((N + 255) / 256), dim3(256), 0, s, dout, dbias, B, N, accumulate);
   if (dtemb) hipLaunchKernelGGL(silu_linear_dx_k, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, s, temb, w, dout, dtemb, B, K, N);
   return check_launch("afd_silu_linear_bwd");

@@ -1,6 +1,7 @@
 """GPU parity tests, model level: blocks, whole UNet, train step and sampling loop on the HIP engine
 against golden vectors produced by the reference's CPU path (tests/golden/make_golden.py)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -239,6 +240,34 @@ def test_graph_step_matches_eager_step_bitwise(A):
         a = ops.denoise_step(x, eps, nz, diff.alpha, diff.alpha_hat, diff.beta, 437)
         b = ops.denoise_step_dev(x, eps, nz, diff.alpha, diff.alpha_hat, diff.beta, t, torch.empty_like(x))
     assert torch.equal(a, b)
+
+
+def test_ddpm_run_drop_in_end_to_end(A, tmp_path, monkeypatch):
+    """Train.ipynb's entry point with its 21 params keys on a tiny synthetic MNIST CSV: train 1 epoch, reload
+    the checkpoint, sample, write PNGs + collage, settings text and loss CSV in the reference's layout."""
+    afdm, dev = A
+    rng = np.random.default_rng(0)
+    csvp = tmp_path / "mnist.csv"
+    arr = np.concatenate([rng.integers(0, 10, (16, 1)), rng.integers(0, 256, (16, 784))], axis=1)
+    np.savetxt(csvp, arr, fmt="%d", delimiter=",", header=",".join(["label"] + [f"p{i}" for i in range(784)]), comments="")
+    monkeypatch.chdir(tmp_path)
+    params = {"unet_v": 3, "dataset": "MNIST", "epochs": 1, "batchsize": 8, "image_size": 32, "image_channels": 1,
+              "device": "cuda", "lr": 3e-4, "noise_steps": 12, "image_gen_per_epoch": 2, "dataset_dir": str(csvp),
+              "f_kernel": 3, "f_beta": 2, "f_down": math.pi / 2, "f_up": math.pi / 2, "save_trining": False,
+              "gen_per_batch": 4, "gen_total": 4, "collage_n_per_image": 4, "collage_n": 4, "seed": 42}
+    out = afdm.ddpm_run(params)
+    run = "DDPM_Uncondtional_MNIST_3"
+    assert len(out["loss_all"]) == 1 and np.isfinite(out["loss_all"][0])
+    assert (tmp_path / "models" / run / "ckpt_MNIST_3.pt").exists()
+    assert (tmp_path / "results" / run / "0.jpg").exists()
+    txt = (tmp_path / "runs" / run / "settings_MNIST_3.txt").read_text()
+    assert txt.splitlines()[0] == "unet_v: 3" and "batch_size : 8" in txt and "kernel_size: 3" in txt
+    assert (tmp_path / "runs" / run / "trining_loss_MNIST_3.csv").exists()
+    assert (tmp_path / "images" / "generated" / "MNIST_3" / "image_3.png").exists()
+    assert os.path.exists(str(tmp_path / "images" / "generated" / "MNIST_3") + "_collage_0.png")
+    assert tuple(out["sample"].shape) == (6, 1, 32, 32) and tuple(out["revert"].shape) == (1, 1, 32, 32)
+    sd = torch.load(tmp_path / "models" / run / "ckpt_MNIST_3.pt", weights_only=True)
+    assert len(sd) == 182        # reference checkpoint wire format: same 182 keys
 
 
 def test_two_rank_data_parallel_equals_single_rank(A, tmp_path):

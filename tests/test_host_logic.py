@@ -100,8 +100,39 @@ def test_modules_shim_resolves_reference_import_paths():
     from modules.ddpm_utils import train, argument, DoubleConv_F, Down_FFF, SelfAttention   # noqa: F401
     from modules.filtrs import circularLowpassKernel, custom_upsample, custom_downsample     # noqa: F401
     from modules.utils import set_seed, setup_logging                                      # noqa: F401
+    from modules.ddpm_tasks import ddpm_run, rotation_results                               # noqa: F401  (Train.ipynb:23)
     import afdm
     assert UNet is afdm.UNet and Diffusion is afdm.Diffusion
+
+
+def _write_mnist_csv(path, n=24):
+    rng = np.random.default_rng(0)
+    arr = np.concatenate([rng.integers(0, 10, (n, 1)), rng.integers(0, 256, (n, 784))], axis=1)
+    header = ",".join(["label"] + [f"p{i}" for i in range(784)])
+    np.savetxt(path, arr, fmt="%d", delimiter=",", header=header, comments="")
+
+
+def test_loaders_without_torchvision(tmp_path):
+    import afdm
+    from PIL import Image
+    csvp = tmp_path / "mnist.csv"
+    _write_mnist_csv(csvp)
+    a = afdm.argument(batch_size=8, dataset_path=str(csvp))
+    dl, ds = afdm.get_data_MNIST(a)
+    xb, yb = next(iter(dl))
+    assert tuple(xb.shape) == (8, 1, 32, 32) and xb.min() >= -1.0 - 1e-6 and xb.max() <= 1.0 + 1e-6 and len(ds) == 24
+    root = tmp_path / "imgs"
+    for c in ("a", "b"):
+        (root / c).mkdir(parents=True)
+        for i in range(3):
+            Image.fromarray(np.random.default_rng(i).integers(0, 255, (40, 48, 3), dtype=np.uint8)).save(root / c / f"{i}.png")
+    a = afdm.argument(batch_size=4, dataset_path=str(root), image_size=32)
+    dl, ds = afdm.get_data(a)
+    assert len(ds) == 6 and ds[0][0].shape[0] == 3 and min(ds[0][0].shape[1:]) == 32
+    out = tmp_path / "gen"
+    afdm.save_gen_images(str(out), torch.randint(0, 255, (4, 3, 32, 32), dtype=torch.uint8), np.arange(4))
+    afdm.make_collage(str(out), str(out), 4, 4, 32)
+    assert (out / "image_3.png").exists() and os.path.exists(str(out) + "_collage_0.png")
 
 
 def test_two_rank_gloo_gradient_exchange(tmp_path):
