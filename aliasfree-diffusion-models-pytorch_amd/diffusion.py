@@ -158,17 +158,22 @@ class Diffusion:
         model.train()
         return ops.quantize_u8(x)
 
-    # F17 (Config E): the reference rotates on the CPU with scipy every step; so do we, for now
-    # (SURVEY.md section 8f-3 lists the GPU spline as a later row).
+    # F17 (Config E): the reference rotates on the CPU with scipy every step (D2H, single-threaded spline,
+    # H2D).  For device tensors the same order-3 / grid-wrap / prefiltered spline runs in a HIP kernel (fp64).
     @staticmethod
     def rotate_2d_matrix(matrix, degrees, filter=None):
+        if matrix.is_cuda:
+            return ops.rotate_spline3_wrap(matrix, degrees)
         from scipy import ndimage
-        dev = matrix.device
-        r = ndimage.rotate(input=matrix.cpu().numpy(), angle=degrees, axes=(2, 3), reshape=False, mode="grid-wrap")
-        return torch.from_numpy(r).to(dev)
+        r = ndimage.rotate(input=matrix.numpy(), angle=degrees, axes=(2, 3), reshape=False, mode="grid-wrap")
+        return torch.from_numpy(r)
 
     @staticmethod
     def shift_2d_matrix(matrix, hshift, vshift, device):
+        """ndimage.shift(x, (0,0,v,h), mode='grid-wrap') (ddpm_models.py:431-436).  The reference only ever
+        shifts by whole pixels (:415), where the periodic spline shift is exactly a roll: done on the device."""
+        if matrix.is_cuda and float(hshift).is_integer() and float(vshift).is_integer():
+            return torch.roll(matrix, shifts=(int(vshift), int(hshift)), dims=(2, 3)).to(device)
         from scipy import ndimage
         r = ndimage.shift(input=matrix.cpu().numpy(), shift=(0, 0, vshift, hshift), mode="grid-wrap")
         return torch.from_numpy(r).to(device)

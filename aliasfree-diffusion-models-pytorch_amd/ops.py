@@ -539,6 +539,25 @@ def quantize_u8(x):
     return out
 
 
+def rotate_spline3_wrap(x, degrees):
+    """scipy.ndimage.rotate(x, degrees, axes=(2,3), reshape=False, order=3, mode='grid-wrap') on the device."""
+    import math
+    _chk(x)
+    x = _c(x)
+    n, c, H, W = x.shape
+    a = np.deg2rad(degrees)
+    cs, sn = math.cos(a), math.sin(a)
+    m = np.array([[cs, sn], [-sn, cs]], dtype=np.float64)                  # scipy.ndimage.rotate's rot_matrix
+    plane = np.array([H, W], dtype=np.float64)
+    off = (plane - 1) / 2 - m @ ((plane - 1) / 2)                           # in_center - rot @ out_center
+    m = np.ascontiguousarray(m)
+    off = np.ascontiguousarray(off)
+    y = torch.empty_like(x)
+    ws = torch.empty(n * c * H * W, device=x.device, dtype=torch.float64)
+    lib().afd_affine_spline3_wrap(_p(x), _p(y), n * c, H, W, m.ctypes.data, off.ctypes.data, _p(ws), _stream())
+    return y
+
+
 class MseLoss(torch.autograd.Function):
     """nn.MSELoss() (mean reduction), deterministic two-stage sum  (ddpm_utils.py:490,503)."""
 

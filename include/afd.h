@@ -173,6 +173,14 @@ int afd_denoise_step_dev(const float* x, const float* eps_pred, const float* noi
                          float* x_out, long n, afd_stream_t stream);
 int afd_quantize_u8(const float* x, uint8_t* out, long n, afd_stream_t stream);
 
+/* ---- F17 (Config E): scipy.ndimage.rotate(order=3, mode='grid-wrap', prefilter=True) per (H,W) plane ----
+ * ddpm_models.py:421-429.  in_coord = M @ out_coord + offset (row, col); matrix4 / offset2 are HOST doubles built
+ * exactly as scipy.ndimage.rotate builds them; fp64 prefilter + interpolation, one rounding to fp32.
+ * workspace: afd_rotate_workspace_bytes(planes, H, W). */
+size_t afd_rotate_workspace_bytes(long planes, int H, int W);
+int afd_affine_spline3_wrap(const float* x, float* y, long planes, int H, int W, const double* matrix4, const double* offset2,
+                            void* workspace, afd_stream_t stream);
+
 /* ---- F15: loss + optimiser ------------------------------------------- ddpm_utils.py:489-490,503-507
  * mse: loss_out[0] = mean((pred-target)^2) (deterministic two-stage reduction; workspace >= 4096 floats);
  * mse_bwd: dpred = 2*(pred-target)/n * dloss[0].

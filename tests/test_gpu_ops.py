@@ -401,6 +401,25 @@ def test_noise_denoise_quantise_bit_exact(A):
     assert torch.equal(ops.quantize_u8(T(g["quant_in"]).to(dev)).cpu(), T(g["quant_out"]))
 
 
+def test_gpu_spline_rotate_vs_scipy_golden(A):
+    """Config E rotation kernel vs fixtures made with scipy.ndimage.rotate through the reference's own
+    Diffusion.rotate_2d_matrix (angles theta/T for theta = +-90, 22.5 and a large 7.5 degrees)."""
+    afdm, ops, dev = A
+    g = load_golden("sample.npz")
+    m = T(g["rot_in"]).to(dev)
+    worst = 0.0
+    for ai in range(4):
+        out = afdm.Diffusion.rotate_2d_matrix(m, float(g[f"rot_angle_{ai}"])).cpu().numpy()
+        err = np.abs(out.astype(np.float64) - g[f"rot_out_{ai}"].astype(np.float64)).max()
+        worst = max(worst, err)
+        assert err < 5e-7, (ai, err)
+        flips = (out != g[f"rot_out_{ai}"]).mean()
+        assert flips < 0.02, (ai, flips)        # fp64 pipeline, one rounding: identical up to rare last-bit flips
+    print("GPU spline rotate: worst |diff| vs scipy", worst)
+    sh = afdm.Diffusion.shift_2d_matrix(m, 1, 0, dev).cpu().numpy()            # whole-pixel periodic shift == roll
+    assert np.abs(sh - g["shift_out"]).max() < 1e-6
+
+
 def test_mse_and_adamw(A):
     afdm, ops, dev = A
     g = _g(31)
