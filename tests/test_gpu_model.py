@@ -98,6 +98,33 @@ def test_unet_forward_vs_reference(A, variant, c):
     assert rel_l2(y2.detach().cpu(), y.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("variant", [3, 0])
+def test_unet_image_size_64_default_constructor_shapes(A, variant):
+    """The reference's default UNet(image_size=64): 64x64 maps, 64..512 channels, L=4096 attention, GroupNorm
+    samples beyond the register path.  Forward and one parameter gradient vs the CPU oracle (B=1)."""
+    afdm, dev = A
+    from oracle import ref_ops as R
+    afdm.set_seed(1)
+    net = afdm.UNet(c_in=3, c_out=3, image_size=64, f_settings=dict(F_SET) if variant else None, device=dev, variant=variant)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(dev)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 3, 64, 64, generator=g)
+    t = torch.tensor([321])
+    y = net(x.to(dev), t.to(dev))
+    with torch.no_grad():
+        ref = R.unet_forward(sd, x, t, variant, F_SET)
+    err = rel_l2(y.detach().cpu(), ref)
+    print(f"image_size=64 variant {variant}: fwd rel-L2 vs oracle {err:.2e}")
+    assert err < 1e-5
+    dy = torch.randn(y.shape, generator=g)
+    (gw,) = torch.autograd.grad(y, net.inc.conv1.weight if variant else net.inc.double_conv[0].weight, dy.to(dev))
+    key = "inc.conv1.weight" if variant else "inc.double_conv.0.weight"
+    sdg = {k: v.clone().requires_grad_(k == key) for k, v in sd.items()}
+    (gref,) = torch.autograd.grad(R.unet_forward(sdg, x, t, variant, F_SET), sdg[key], dy)
+    assert rel_l2(gw.cpu(), gref) < 1e-4
+
+
 def test_unet_variant4_runs_and_matches_reference(A):
     afdm, dev = A
     g = load_golden("unet_fwd.npz")
