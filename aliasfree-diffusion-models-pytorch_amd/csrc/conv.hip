@@ -508,7 +508,8 @@ __global__ __launch_bounds__(256) void conv_mfma_sk(const float* __restrict__ x,
 // ------------------------------------------------------------------------------------------
 template <int T, int WNn, int WCn, int NPB>
 __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ dy,
-                                                       float* __restrict__ part, int B, int Cin, int Cout, int H, int W,
+                                                       float* __restrict__ part, float* __restrict__ bias_part,
+                                                       int B, int Cin, int Cout, int H, int W,
                                                        int chunks_per_split, int nchunks, TileGeom g) {
   constexpr int PT = 64, HALO = (T == 9) ? 1 : 0, S1 = PT + 1;
   constexpr int WK = 4 / (WNn * WCn), BNo = 32 * WNn, BCi = 32 * WCn;
@@ -597,6 +598,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const bool do_bias = bias_part != nullptr && blockIdx.y == 0;          // one cin-tile per (cout tile, split) sums dY
+  float bsum = 0.f;
 
   const int cbeg = split * chunks_per_split;
   const int cend = min(nchunks, cbeg + chunks_per_split);
@@ -606,6 +609,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
     commit();
     __syncthreads();
     if (ch + 1 < cend) fetch(ch + 1);                                   // in flight during the MFMAs
+    if (do_bias) {                                                      // dbias: row sums of the dY tile (4 threads per row)
+      const int bn = threadIdx.x >> 2, bq = threadIdx.x & 3;
+      if (bn < BNo) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += Gs[bn * S1 + bq * 16 + j];
+        bsum += t;
+      }
+    }
     if (active) {
 #pragma unroll 2
       for (int s = wk * (PT / 2 / WK); s < (wk + 1) * (PT / 2 / WK); ++s) {
@@ -619,6 +631,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
         }
       }
     }
+  }
+  if (do_bias) {                                                        // slab tail: bias_part[split][Cout]
+    float t = bsum;
+    t += __shfl_xor(t, 1, kWave);
+    t += __shfl_xor(t, 2, kWave);
+    const int bn = threadIdx.x >> 2;
+    if ((threadIdx.x & 3) == 0 && bn < BNo && n0 + bn < Cout) bias_part[(long)split * Cout + n0 + bn] = t;
   }
   float* out = part + (long)split * Cout * Cin * T;
   if (WK == 1) {
@@ -657,27 +676,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
   }
 }
 
-// dw[i] (+)= sum_k part[k][i]: 256 threads = 32 consecutive elements x 8 slab groups (fixed order)
-__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, long n, int splits, int accumulate) {
+// dw[i] (+)= sum_k part[k][i] and (optionally) db[j] (+)= sum_k bias_part[k][j] in ONE launch:
+// 256 threads = 32 consecutive elements x 8 slab groups (fixed order); elements i >= n are the bias row.
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, long n, int splits,
+                                                    const float* __restrict__ bias_part, float* __restrict__ db, int nb,
+                                                    int accumulate) {
   __shared__ float red[8][33];
   const long i = (long)blockIdx.x * 32 + (threadIdx.x & 31);
   const int g = threadIdx.x >> 5;
+  const bool isw = i < n;
+  const long j = isw ? i : i - n;
+  const long stride = isw ? n : nb;
+  const float* __restrict__ src = isw ? part : bias_part;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (i < n) {
+  if (i < n + nb) {
     int k = g;
     for (; k + 24 < splits; k += 32) {
-      s0 += part[(long)k * n + i]; s1 += part[(long)(k + 8) * n + i];
-      s2 += part[(long)(k + 16) * n + i]; s3 += part[(long)(k + 24) * n + i];
+      s0 += src[(long)k * stride + j]; s1 += src[(long)(k + 8) * stride + j];
+      s2 += src[(long)(k + 16) * stride + j]; s3 += src[(long)(k + 24) * stride + j];
     }
-    for (; k < splits; k += 8) s0 += part[(long)k * n + i];
+    for (; k < splits; k += 8) s0 += src[(long)k * stride + j];
   }
   red[g][threadIdx.x & 31] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (g == 0 && i < n) {
+  if (g == 0 && i < n + nb) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
-    dw[i] = accumulate ? dw[i] + t : t;
+    float* o = isw ? dw + j : db + j;
+    *o = accumulate ? *o + t : t;
   }
 }
 
@@ -758,21 +785,21 @@ static inline WgradPlan wgrad_plan(int B, int Cin, int Cout, int H, int W, int k
 }
 
 template <int T, int WNn, int WCn, int NPB>
-static void launch_wgrad(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W,
+static void launch_wgrad(const float* x, const float* dy, float* part, float* bias_part, int B, int Cin, int Cout, int H, int W,
                          const WgradPlan& p, const TileGeom& g, hipStream_t s) {
   size_t lds = sizeof(float) * ((size_t)32 * WNn * 65 + (size_t)32 * WCn * (g.XS | 1)) + sizeof(int) * 64;
   if (WNn * WCn < 4 && lds < sizeof(float) * 4 * 16 * 64) lds = sizeof(float) * 4 * 16 * 64;      // cross-wave reduce buffer
   const dim3 grid((Cout + 32 * WNn - 1) / (32 * WNn), (Cin + 32 * WCn - 1) / (32 * WCn), p.splits);
-  hipLaunchKernelGGL((conv_wgrad_mfma<T, WNn, WCn, NPB>), grid, dim3(256), lds, s, x, dy, part, B, Cin, Cout, H, W, p.cps, p.nchunks, g);
+  hipLaunchKernelGGL((conv_wgrad_mfma<T, WNn, WCn, NPB>), grid, dim3(256), lds, s, x, dy, part, bias_part, B, Cin, Cout, H, W, p.cps, p.nchunks, g);
 }
 
 template <int T, int NPB>
-static void launch_wgrad_roles(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W,
+static void launch_wgrad_roles(const float* x, const float* dy, float* part, float* bp, int B, int Cin, int Cout, int H, int W,
                                const WgradPlan& p, const TileGeom& g, hipStream_t s) {
-  if (p.wnn == 2 && p.wcn == 2) launch_wgrad<T, 2, 2, NPB>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
-  else if (p.wnn == 2) launch_wgrad<T, 2, 1, NPB>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
-  else if (p.wcn == 2) launch_wgrad<T, 1, 2, NPB>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
-  else launch_wgrad<T, 1, 1, NPB>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
+  if (p.wnn == 2 && p.wcn == 2) launch_wgrad<T, 2, 2, NPB>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
+  else if (p.wnn == 2) launch_wgrad<T, 2, 1, NPB>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
+  else if (p.wcn == 2) launch_wgrad<T, 1, 2, NPB>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
+  else launch_wgrad<T, 1, 1, NPB>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
 }
 
 }  // namespace afd
@@ -823,7 +850,11 @@ int afd_conv_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, i
 size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ksize) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
   if (!tile_ok(H, W, 64)) return sizeof(float) * (size_t)B * Cout;
-  return sizeof(float) * ((size_t)wgrad_plan(B, Cin, Cout, H, W, ksize).slabs * Cout * Cin * ksize * ksize + (size_t)B * Cout);
+  // [slabs][Cout*Cin*T] weight slabs, then [slabs][Cout] bias slabs; the direct path wants (B, Cout) plane sums
+  const size_t slabs = wgrad_plan(B, Cin, Cout, H, W, ksize).slabs;
+  const size_t need = slabs * ((size_t)Cout * Cin * ksize * ksize + Cout);
+  const size_t direct = (size_t)B * Cout;
+  return sizeof(float) * (need > direct ? need : direct);
 }
 
 int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
@@ -837,22 +868,23 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
     AFD_REQUIRE(workspace, "afd_conv_wgrad: workspace is NULL");
     const WgradPlan p = wgrad_plan(B, Cin, Cout, H, W, ksize);
     float* part = static_cast<float*>(workspace);
-    if (ksize == 1) launch_wgrad_roles<1, 2>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
-    else if (p.npb == 4) launch_wgrad_roles<9, 4>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
-    else if (p.npb == 5) launch_wgrad_roles<9, 5>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
-    else launch_wgrad_roles<9, 8>(x, dy, part, B, Cin, Cout, H, W, p, g, s);
     const long n = (long)Cout * Cin * T;
-    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, part, dw, n, p.slabs, accumulate);
+    float* bp = dbias ? part + (size_t)p.slabs * n : nullptr;           // bias slabs behind the weight slabs
+    if (ksize == 1) launch_wgrad_roles<1, 2>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
+    else if (p.npb == 4) launch_wgrad_roles<9, 4>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
+    else if (p.npb == 5) launch_wgrad_roles<9, 5>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
+    else launch_wgrad_roles<9, 8>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
+    const long tot = n + (dbias ? Cout : 0);
+    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((tot + 31) / 32)), dim3(256), 0, s, part, dw, n, p.slabs, bp, dbias, dbias ? Cout : 0, accumulate);
+    return check_launch("afd_conv_wgrad");
   } else {
     const dim3 grid((unsigned)(Cout * Cin));
     if (ksize == 3) hipLaunchKernelGGL(conv_direct_wgrad<3>, grid, dim3(256), 0, s, x, dy, dw, B, Cin, Cout, H, W, accumulate);
     else hipLaunchKernelGGL(conv_direct_wgrad<1>, grid, dim3(256), 0, s, x, dy, dw, B, Cin, Cout, H, W, accumulate);
   }
-  if (dbias) {
+  if (dbias) {                                                            // direct path only: plane sums + column sum
     AFD_REQUIRE(workspace, "afd_conv_wgrad: workspace is NULL");
-    // the (B, Cout) plane partials live at the END of the workspace (after the split-K slabs)
-    const size_t wsz = afd_conv_wgrad_workspace_bytes(B, Cin, Cout, H, W, ksize) / sizeof(float);
-    float* bp = static_cast<float*>(workspace) + (wsz - (size_t)B * Cout);
+    float* bp = static_cast<float*>(workspace);
     const long planes = (long)B * Cout;
     hipLaunchKernelGGL(conv_dbias_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, dy, bp, planes, H * W);
     hipLaunchKernelGGL(conv_dbias_final, dim3((Cout + 31) / 32), dim3(256), 0, s, bp, dbias, B, Cout, accumulate);
