@@ -21,20 +21,38 @@ namespace afd {
 constexpr int kTile = 64;      // rows of the streamed operand per LDS tile
 constexpr int kChunk = 8;      // keys per online-softmax rescale
 
-template <int D> struct RowVec {                 // one [d] row in LDS, read as b128 / b64 broadcasts
-  static __device__ __forceinline__ void load(const float* __restrict__ p, float (&v)[D]) {
+// All d-length dot products and rank-d updates run on register PAIRS (v_pk_fma_f32 / v_pk_mul_f32, scalar operands
+// broadcast through op_sel): measured on MI355X a packed FMA issues in 5.4 cycles against 4.3 for v_fma_f32
+// (tools/micro/pk_rate.hip), i.e. 1.6x the FMA rate of the scalar form.  Scores live in the log2 domain
+// (log2(e)/sqrt(d) folded into Q) so the exponential is one v_exp_f32.
+using f2 = __attribute__((ext_vector_type(2))) float;
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+
+template <int D> struct RowVec {                 // one [d] row in LDS, read as b128 / b64 broadcasts into D/2 pairs
+  static __device__ __forceinline__ void load(const float* __restrict__ p, f2 (&v)[D / 2]) {
     if constexpr (D % 4 == 0) {
 #pragma unroll
       for (int j = 0; j < D / 4; ++j) {
         const float4 t = reinterpret_cast<const float4*>(p)[j];
-        v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+        v[2 * j] = (f2){t.x, t.y}; v[2 * j + 1] = (f2){t.z, t.w};
       }
     } else {
       const float2 t = *reinterpret_cast<const float2*>(p);
-      v[0] = t.x; v[1] = t.y;
+      v[0] = (f2){t.x, t.y};
     }
   }
 };
+template <int P> __device__ __forceinline__ float dot2(const f2 (&a)[P], const f2 (&b)[P]) {
+  f2 t = a[0] * b[0];
+#pragma unroll
+  for (int i = 1; i < P; ++i) t = __builtin_elementwise_fma(a[i], b[i], t);
+  return t.x + t.y;
+}
+template <int P> __device__ __forceinline__ void axpy2(f2 (&acc)[P], float s, const f2 (&v)[P]) {
+  const f2 ss = {s, s};
+#pragma unroll
+  for (int i = 0; i < P; ++i) acc[i] = __builtin_elementwise_fma(ss, v[i], acc[i]);
+}
 
 // stage rows [r0, r0+kTile) of a (D, L) j-major operand into LDS as [row][D] (optionally scaled)
 template <int D>
@@ -48,6 +66,7 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ src, float*
 template <int D, int R>
 __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv, float* __restrict__ o,
                                                   float* __restrict__ lse, int heads, int L, float scale) {
+  constexpr int P = D / 2;
   __shared__ __attribute__((aligned(16))) float Ks[kTile * D];
   __shared__ __attribute__((aligned(16))) float Vs[kTile * D];
   const int b = blockIdx.z, h = blockIdx.y;
@@ -56,13 +75,16 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv,
   const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
   const float* kp = qp + (long)C * L;
   const float* vp = kp + (long)C * L;
-  float q[R][D], acc[R][D], m[R], l[R];
+  f2 q[R][P], acc[R][P];
+  float m[R], l[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int qi = q0 + r * blockDim.x;
     m[r] = -INFINITY; l[r] = 0.f;
 #pragma unroll
-    for (int j = 0; j < D; ++j) { q[r][j] = qi < L ? qp[(long)j * L + qi] * scale : 0.f; acc[r][j] = 0.f; }
+    for (int j = 0; j < D; ++j) q[r][j >> 1][j & 1] = qi < L ? qp[(long)j * L + qi] * (scale * kLog2e) : 0.f;
+#pragma unroll
+    for (int i = 0; i < P; ++i) acc[r][i] = (f2){0.f, 0.f};
   }
   for (int k0 = 0; k0 < L; k0 += kTile) {
     __syncthreads();
@@ -76,36 +98,32 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv,
       for (int r = 0; r < R; ++r) cm[r] = m[r];
 #pragma unroll
       for (int u = 0; u < kChunk; ++u) {
-        float kv[D];
+        f2 kv[P];
         RowVec<D>::load(Ks + (c0 + u) * D, kv);
         const bool in = c0 + u < nk;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          float a = 0.f;
-#pragma unroll
-          for (int j = 0; j < D; ++j) a += q[r][j] * kv[j];
-          s[r][u] = in ? a : -INFINITY;
+          s[r][u] = in ? dot2<P>(q[r], kv) : -INFINITY;
           cm[r] = fmaxf(cm[r], s[r][u]);
         }
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const float alpha = __expf(m[r] - cm[r]);      // m = -inf on the first chunk -> 0
+        const float alpha = __builtin_amdgcn_exp2f(m[r] - cm[r]);      // m = -inf on the first chunk -> 0
         l[r] *= alpha;
 #pragma unroll
-        for (int j = 0; j < D; ++j) acc[r][j] *= alpha;
+        for (int i = 0; i < P; ++i) acc[r][i] *= alpha;
         m[r] = cm[r];
       }
 #pragma unroll
       for (int u = 0; u < kChunk; ++u) {
-        float vv[D];
+        f2 vv[P];
         RowVec<D>::load(Vs + (c0 + u) * D, vv);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const float p = __expf(s[r][u] - cm[r]);
+          const float p = __builtin_amdgcn_exp2f(s[r][u] - cm[r]);
           l[r] += p;
-#pragma unroll
-          for (int j = 0; j < D; ++j) acc[r][j] += p * vv[j];
+          axpy2<P>(acc[r], p, vv);
         }
       }
     }
@@ -117,8 +135,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv,
       const float inv = 1.0f / l[r];
       float* op = o + ((long)b * C + h * D) * L + qi;
 #pragma unroll
-      for (int j = 0; j < D; ++j) op[(long)j * L] = acc[r][j] * inv;
-      lse[((long)b * heads + h) * L + qi] = m[r] + __logf(l[r]);
+      for (int j = 0; j < D; ++j) op[(long)j * L] = acc[r][j >> 1][j & 1] * inv;
+      lse[((long)b * heads + h) * L + qi] = (m[r] + __builtin_amdgcn_logf(l[r])) * kLn2;      // v_log_f32 = log2
     }
   }
 }
@@ -129,6 +147,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
                                                      const float* __restrict__ d_o, const float* __restrict__ lse,
                                                      float* __restrict__ dqkv, float* __restrict__ delta_out,
                                                      int heads, int L, float scale) {
+  constexpr int P = D / 2;
   __shared__ __attribute__((aligned(16))) float Ks[kTile * D];
   __shared__ __attribute__((aligned(16))) float Vs[kTile * D];
   const int b = blockIdx.z, h = blockIdx.y;
@@ -138,7 +157,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
   const float* kp = qp + (long)C * L;
   const float* vp = kp + (long)C * L;
   const long obase = ((long)b * C + h * D) * L;
-  float q[R][D], go[R][D], dq[R][D], delta[R], ls[R];
+  f2 q[R][P], go[R][P], dq[R][P];
+  float delta[R], ls[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int qi = q0 + r * blockDim.x;
@@ -146,12 +166,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
     delta[r] = 0.f;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      q[r][j] = live ? qp[(long)j * L + qi] * scale : 0.f;
-      go[r][j] = live ? d_o[obase + (long)j * L + qi] : 0.f;
-      delta[r] += go[r][j] * (live ? o[obase + (long)j * L + qi] : 0.f);
-      dq[r][j] = 0.f;
+      const float g = live ? d_o[obase + (long)j * L + qi] : 0.f;
+      q[r][j >> 1][j & 1] = live ? qp[(long)j * L + qi] * (scale * kLog2e) : 0.f;
+      go[r][j >> 1][j & 1] = g;
+      delta[r] += g * (live ? o[obase + (long)j * L + qi] : 0.f);
     }
-    ls[r] = live ? lse[((long)b * heads + h) * L + qi] : 0.f;
+#pragma unroll
+    for (int i = 0; i < P; ++i) dq[r][i] = (f2){0.f, 0.f};
+    ls[r] = live ? lse[((long)b * heads + h) * L + qi] * kLog2e : 0.f;
     if (live) delta_out[((long)b * heads + h) * L + qi] = delta[r];
   }
   for (int k0 = 0; k0 < L; k0 += kTile) {
@@ -162,17 +184,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
     const int nk = min(kTile, L - k0);
 #pragma unroll 2
     for (int u = 0; u < nk; ++u) {
-      float kv[D], vv[D];
+      f2 kv[P], vv[P];
       RowVec<D>::load(Ks + u * D, kv);
       RowVec<D>::load(Vs + u * D, vv);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        float sc = 0.f, dp = 0.f;
-#pragma unroll
-        for (int j = 0; j < D; ++j) { sc += q[r][j] * kv[j]; dp += go[r][j] * vv[j]; }
-        const float ds = __expf(sc - ls[r]) * (dp - delta[r]);
-#pragma unroll
-        for (int j = 0; j < D; ++j) dq[r][j] += ds * kv[j];
+        const float sc = dot2<P>(q[r], kv), dp = dot2<P>(go[r], vv);
+        const float ds = __builtin_amdgcn_exp2f(sc - ls[r]) * (dp - delta[r]);
+        axpy2<P>(dq[r], ds, kv);
       }
     }
   }
@@ -182,16 +201,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
     if (qi < L) {
       float* dqp = dqkv + ((long)b * 3 * C + h * D) * L + qi;
 #pragma unroll
-      for (int j = 0; j < D; ++j) dqp[(long)j * L] = dq[r][j] * scale;
+      for (int j = 0; j < D; ++j) dqp[(long)j * L] = dq[r][j >> 1][j & 1] * scale;
     }
   }
 }
 
-// dK, dV: lane = R key rows; LDS holds a tile of (scale*Q), dO, lse and delta rows.
+// dK, dV: lane = R key rows; LDS holds a tile of (scale*log2e*Q), dO, lse*log2e and delta rows.
 template <int D, int R>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                       float* __restrict__ dqkv, int heads, int L, float scale) {
+  constexpr int P = D / 2;
   __shared__ __attribute__((aligned(16))) float Qs[kTile * D];
   __shared__ __attribute__((aligned(16))) float Gs[kTile * D];
   __shared__ float Ls[kTile];
@@ -205,43 +225,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
   const float* gp = d_o + ((long)b * C + h * D) * L;
   const float* lp = lse + ((long)b * heads + h) * L;
   const float* dlp = delta + ((long)b * heads + h) * L;
-  float k[R][D], v[R][D], dk[R][D], dv[R][D];
+  f2 k[R][P], v[R][P], dk[R][P], dv[R][P];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int ki = kq0 + r * blockDim.x;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      k[r][j] = ki < L ? kp[(long)j * L + ki] : 0.f;
-      v[r][j] = ki < L ? vp[(long)j * L + ki] : 0.f;
-      dk[r][j] = 0.f; dv[r][j] = 0.f;
+      k[r][j >> 1][j & 1] = ki < L ? kp[(long)j * L + ki] : 0.f;
+      v[r][j >> 1][j & 1] = ki < L ? vp[(long)j * L + ki] : 0.f;
     }
+#pragma unroll
+    for (int i = 0; i < P; ++i) { dk[r][i] = (f2){0.f, 0.f}; dv[r][i] = (f2){0.f, 0.f}; }
   }
   for (int t0 = 0; t0 < L; t0 += kTile) {
     __syncthreads();
-    stage_rows<D>(qp, Qs, t0, L, scale);
+    stage_rows<D>(qp, Qs, t0, L, scale * kLog2e);
     stage_rows<D>(gp, Gs, t0, L, 1.f);
     for (int i = threadIdx.x; i < kTile; i += blockDim.x) {
       const bool in = t0 + i < L;
-      Ls[i] = in ? lp[t0 + i] : INFINITY;              // exp(s - inf) = 0 for padded queries
+      Ls[i] = in ? lp[t0 + i] * kLog2e : INFINITY;     // exp2(s - inf) = 0 for padded queries
       Ds[i] = in ? dlp[t0 + i] : 0.f;
     }
     __syncthreads();
     const int nq = min(kTile, L - t0);
 #pragma unroll 2
     for (int u = 0; u < nq; ++u) {
-      float qv[D], gv[D];
+      f2 qv[P], gv[P];
       RowVec<D>::load(Qs + u * D, qv);
       RowVec<D>::load(Gs + u * D, gv);
       const float lsu = Ls[u], dlu = Ds[u];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        float sc = 0.f, dp = 0.f;
-#pragma unroll
-        for (int j = 0; j < D; ++j) { sc += qv[j] * k[r][j]; dp += gv[j] * v[r][j]; }
-        const float p = __expf(sc - lsu);
+        const float sc = dot2<P>(qv, k[r]), dp = dot2<P>(gv, v[r]);
+        const float p = __builtin_amdgcn_exp2f(sc - lsu);
         const float ds = p * (dp - dlu);
-#pragma unroll
-        for (int j = 0; j < D; ++j) { dv[r][j] += p * gv[j]; dk[r][j] += ds * qv[j]; }   // qv already carries `scale`
+        axpy2<P>(dv[r], p, gv);
+        axpy2<P>(dk[r], ds, qv);                       // qv carries scale*log2e; the log2e is taken out at the store
       }
     }
   }
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
       float* dkp = dqkv + ((long)b * 3 * C + C + h * D) * L + ki;
       float* dvp = dkp + (long)C * L;
 #pragma unroll
-      for (int j = 0; j < D; ++j) { dkp[(long)j * L] = dk[r][j]; dvp[(long)j * L] = dv[r][j]; }
+      for (int j = 0; j < D; ++j) { dkp[(long)j * L] = dk[r][j >> 1][j & 1] * kLn2; dvp[(long)j * L] = dv[r][j >> 1][j & 1]; }
     }
   }
 }
@@ -280,7 +299,14 @@ template <int D, int R> static void launch_dkv(const float* qkv, const float* d_
   hipLaunchKernelGGL((attn_bwd_dkv_k<D, R>), grid, block, 0, s, qkv, d_o, lse, delta, dqkv, heads, L, sc);
 }
 
-static int g_attn_rows = 0;      // tuning hook: 0 = default rows per lane, else force R in {1,2,4} for d = 8
+namespace afd {   // attn_mfma.hip: d = 8 passes with the d-contractions on the matrix cores
+bool attn_mfma8_ok(int d, int L);
+void attn_mfma8_fwd(const float* qkv, float* o, float* lse, int B, int heads, int L, float sc, hipStream_t s);
+void attn_mfma8_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta,
+                    int B, int heads, int L, float sc, hipStream_t s);
+}
+static int g_attn_rows = 0;      // tuning hook: 0 = default (MFMA path for d = 8 when L % 256 == 0); 1,2,4 force the
+                                 // all-VALU kernels with that many rows per lane
 
 extern "C" {
 
@@ -296,6 +322,7 @@ int afd_attn_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d
   AFD_REQUIRE(B <= 65535 && heads <= 65535, "afd_attn_fwd: grid too large");
   hipStream_t s = as_stream(st);
   const float sc = 1.0f / sqrtf((float)d);
+  if (g_attn_rows == 0 && attn_mfma8_ok(d, L)) { attn_mfma8_fwd(qkv, o, lse, B, heads, L, sc, s); return check_launch("afd_attn_fwd"); }
   // rows per lane by head dim (register budget): 4,4,4,2,2,1
   switch (d) {
     case 2:  launch_fwd<2, 4>(qkv, o, lse, B, heads, L, sc, s); break;
@@ -320,6 +347,10 @@ int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float
   AFD_REQUIRE(B <= 65535 && heads <= 65535, "afd_attn_bwd: grid too large");
   hipStream_t s = as_stream(st);
   const float sc = 1.0f / sqrtf((float)d);
+  if (g_attn_rows == 0 && attn_mfma8_ok(d, L) && L < 1024) {      // measured: at L = 1024 the all-VALU R=2 pair is 6 % faster
+    attn_mfma8_bwd(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s);
+    return check_launch("afd_attn_bwd");
+  }
   switch (d) {      // dQ pass: rows per lane 4,4,4,2,2,1
     case 2:  launch_dq<2, 4>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); break;
     case 4:  launch_dq<4, 4>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); break;

@@ -506,15 +506,15 @@ __global__ __launch_bounds__(256) void conv_mfma_sk(const float* __restrict__ x,
 //   All 256 threads stage (lane = 32 consecutive tile positions -> 128-B reads); every load of a chunk
 //   is issued before the first wait, and chunk k+1 is fetched while chunk k's 288 MFMAs run.
 // ------------------------------------------------------------------------------------------
-template <int T, int WNn, int WCn, int NPB>
-__global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ dy,
+template <int T, int WNn, int WCn, int NPB, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ dy,
                                                        float* __restrict__ part, float* __restrict__ bias_part,
                                                        int B, int Cin, int Cout, int H, int W,
                                                        int chunks_per_split, int nchunks, TileGeom g) {
   constexpr int PT = 64, HALO = (T == 9) ? 1 : 0, S1 = PT + 1;
-  constexpr int WK = 4 / (WNn * WCn), BNo = 32 * WNn, BCi = 32 * WCn;
-  constexpr int NG = BNo / 4;                        // dY rows per thread
-  constexpr int NM = BCi / 8;                        // channels per thread per position slot
+  constexpr int WK = NW / (WNn * WCn), BNo = 32 * WNn, BCi = 32 * WCn, NT_ = 64 * NW;
+  constexpr int NG = BNo / NW;                       // dY rows per thread
+  constexpr int NM = BCi / (2 * NW);                 // channels per thread per position slot
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int XSP = g.XS | 1;                          // odd channel stride: conflict-free fragment reads
   float* Gs = smem;                                  // [BNo][S1]   dY tile
@@ -532,10 +532,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
   if (threadIdx.x < PT) Po[threadIdx.x] = pix_lds_off(threadIdx.x, W, g, HALO);
 
   // ---- chunk-invariant staging plan
-  const int pp = threadIdx.x & 63, ng = threadIdx.x >> 6;               // dY: pixel pp, rows ng + 4e
+  const int pp = threadIdx.x & 63, ng = threadIdx.x >> 6;               // dY: pixel pp, rows ng + NW*e
   const int gdb = (HW >= PT) ? 0 : pp / HW;
   const int gpix = (HW >= PT) ? pp : pp % HW;
-  const int px = threadIdx.x & 31, cg = threadIdx.x >> 5;               // X: position px + 32e, channels cg + 8m
+  const int px = threadIdx.x & 31, cg = threadIdx.x >> 5;               // X: position px + 32e, channels cg + 2*NW*m
   int p_ti[NPB], p_rr[NPB], p_cc[NPB];
 #pragma unroll
   for (int e = 0; e < NPB; ++e) {
@@ -548,48 +548,53 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
 
   float gv[NG], xv[NPB][NM];
   unsigned gok, xok[NPB];
-  auto fetch = [&](int ch) {
-    const long pc = (long)ch * PT;
+  // running origin of the next chunk to fetch: image, first pixel and first row inside it.  32-bit state advanced by
+  // adds (the host bounds B*H*W*max(C) < 2^31) -- the per-chunk 64-bit divisions this replaces cost ~1 us each.
+  int f_img, f_pix, f_row;
+  auto fetch = [&]() {
     {  // dY
-      const long b = pc / HW + gdb;
-      const int pix = (HW >= PT) ? (int)(pc % HW) + gpix : gpix;
-      const bool pin = (pc + pp) < P;
-      const unsigned gb = pin ? (unsigned)(b * Cout) * (unsigned)HW + (unsigned)pix : 0u;
+      const int b = f_img + gdb;
+      const bool pin = b < B;
+      const unsigned gb = pin ? (unsigned)(b * Cout) * (unsigned)HW + (unsigned)(f_pix + gpix) : 0u;
       gok = 0;
 #pragma unroll
       for (int e = 0; e < NG; ++e) {
-        const int n = n0 + ng + 4 * e;
+        const int n = n0 + ng + NW * e;
         gv[e] = dy[gb + (unsigned)(min(n, Cout - 1) * HW)];
         gok |= ((pin && n < Cout) ? 1u : 0u) << e;
       }
     }
-    const long img0 = pc / HW;
-    const int row0 = (int)((pc % HW) / W);
 #pragma unroll
     for (int e = 0; e < NPB; ++e) {
       xok[e] = 0;
       if (p_ti[e] >= 0) {
-        const long img = img0 + p_ti[e];
-        const int yy = row0 + p_rr[e];
-        const bool ok = p_cc[e] >= 0 && p_cc[e] < W && yy >= 0 && yy < H && img * HW < P;
+        const int img = f_img + p_ti[e];
+        const int yy = f_row + p_rr[e];
+        const bool ok = p_cc[e] >= 0 && p_cc[e] < W && yy >= 0 && yy < H && img < B;
         const unsigned xb = ok ? (unsigned)(img * Cin) * (unsigned)HW + (unsigned)(yy * W + p_cc[e]) : 0u;
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
-          const int c = c0 + cg + 8 * m;
+          const int c = c0 + cg + 2 * NW * m;
           xv[e][m] = x[xb + (unsigned)(min(c, Cin - 1) * HW)];
           xok[e] |= ((ok && c < Cin) ? 1u : 0u) << m;
         }
       }
     }
+    if (HW >= PT) {
+      f_pix += PT; f_row += g.TR;
+      if (f_pix >= HW) { f_pix = 0; f_row = 0; ++f_img; }
+    } else {
+      f_img += g.TI;
+    }
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int e = 0; e < NG; ++e) Gs[(ng + 4 * e) * S1 + pp] = ((gok >> e) & 1u) ? gv[e] : 0.f;
+    for (int e = 0; e < NG; ++e) Gs[(ng + NW * e) * S1 + pp] = ((gok >> e) & 1u) ? gv[e] : 0.f;
 #pragma unroll
     for (int e = 0; e < NPB; ++e)
       if (p_ti[e] >= 0) {
 #pragma unroll
-        for (int m = 0; m < NM; ++m) Xs[(cg + 8 * m) * XSP + px + 32 * e] = ((xok[e] >> m) & 1u) ? xv[e][m] : 0.f;
+        for (int m = 0; m < NM; ++m) Xs[(cg + 2 * NW * m) * XSP + px + 32 * e] = ((xok[e] >> m) & 1u) ? xv[e][m] : 0.f;
       }
   };
 
@@ -603,12 +608,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
 
   const int cbeg = split * chunks_per_split;
   const int cend = min(nchunks, cbeg + chunks_per_split);
-  if (cbeg < cend) fetch(cbeg);
+  {
+    const unsigned pc0 = (unsigned)cbeg * PT;
+    f_img = (int)(pc0 / (unsigned)HW);
+    f_pix = (int)(pc0 % (unsigned)HW);
+    f_row = f_pix / W;
+  }
+  if (cbeg < cend) fetch();
   for (int ch = cbeg; ch < cend; ++ch) {
     __syncthreads();
     commit();
     __syncthreads();
-    if (ch + 1 < cend) fetch(ch + 1);                                   // in flight during the MFMAs
+    if (ch + 1 < cend) fetch();                                   // in flight during the MFMAs
     if (do_bias) {                                                      // dbias: row sums of the dY tile (4 threads per row)
       const int bn = threadIdx.x >> 2, bq = threadIdx.x & 3;
       if (bn < BNo) {
@@ -619,7 +630,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
       }
     }
     if (active) {
-#pragma unroll 2
+#pragma unroll 4
       for (int s = wk * (PT / 2 / WK); s < (wk + 1) * (PT / 2 / WK); ++s) {
         const int pix = 2 * s + half;
         const float a = Gs[(nw + l31) * S1 + pix];
@@ -649,12 +660,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
         const int n = n0 + nw + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (n >= Cout) continue;
 #pragma unroll
-        for (int t = 0; t < T; ++t) out[((long)n * Cin + ci) * T + t] = acc[t][r];
+        for (int t = 0; t < T; ++t) out[((long)t * Cout + n) * Cin + ci] = acc[t][r];      // slab layout [tap][cout][cin]: 128-B rows
       }
     }
   } else {
     // the WK waves that share an output block meet in LDS, one tap at a time (fixed order: deterministic)
-    float* red = smem;                                  // [4 waves][16][64]
+    float* red = smem;                                  // [NW waves][16][64]
     constexpr int NB = WNn * WCn;                       // distinct output blocks in this workgroup (1 or 2)
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -662,7 +673,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[(wv * 16 + r) * 64 + lane] = acc[t][r];
       __syncthreads();
-      for (int idx = threadIdx.x; idx < NB * 1024; idx += 256) {
+      for (int idx = threadIdx.x; idx < NB * 1024; idx += NT_) {
         const int blk = idx / 1024, r = (idx / 64) % 16, ln = idx % 64;
         float v = 0.f;
 #pragma unroll
@@ -670,7 +681,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
         const int bn = blk % WNn, bc = blk / WNn;
         const int n = n0 + bn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
         const int ci = c0 + bc * 32 + (ln & 31);
-        if (n < Cout && ci < Cin) out[((long)n * Cin + ci) * T + t] = v;
+        if (n < Cout && ci < Cin) out[((long)t * Cout + n) * Cin + ci] = v;
       }
     }
   }
@@ -678,9 +689,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma(const float* __restrict__
 
 // dw[i] (+)= sum_k part[k][i] and (optionally) db[j] (+)= sum_k bias_part[k][j] in ONE launch:
 // 256 threads = 32 consecutive elements x 8 slab groups (fixed order); elements i >= n are the bias row.
+// Slabs are [tap][cout][cin] (coalesced stores from the accumulator layout); dw is OIHW, so element i = (t, n*Cin+ci)
+// lands at (n*Cin+ci)*T + t.
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, long n, int splits,
                                                     const float* __restrict__ bias_part, float* __restrict__ db, int nb,
-                                                    int accumulate) {
+                                                    int accumulate, int T) {
   __shared__ float red[8][33];
   const long i = (long)blockIdx.x * 32 + (threadIdx.x & 31);
   const int g = threadIdx.x >> 5;
@@ -703,7 +716,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
-    float* o = isw ? dw + j : db + j;
+    const long plane = n / T;
+    float* o = isw ? dw + (j % plane) * T + j / plane : db + j;
     *o = accumulate ? *o + t : t;
   }
 }
@@ -764,6 +778,7 @@ static int launch_mfma(const float* x, const float* w, const float* bias, const 
   return 0;
 }
 
+static int g_wgrad_nw = 0;        // tuning hook: waves per wgrad workgroup (0 = default 8)
 struct WgradPlan { int wnn, wcn, wk, splits, slabs, nchunks, cps, npb; };
 static inline WgradPlan wgrad_plan(int B, int Cin, int Cout, int H, int W, int ksize) {
   WgradPlan p;
@@ -787,10 +802,17 @@ static inline WgradPlan wgrad_plan(int B, int Cin, int Cout, int H, int W, int k
 template <int T, int WNn, int WCn, int NPB>
 static void launch_wgrad(const float* x, const float* dy, float* part, float* bias_part, int B, int Cin, int Cout, int H, int W,
                          const WgradPlan& p, const TileGeom& g, hipStream_t s) {
+  // 8 waves (two per SIMD: one wave's staging and epilogue overlap the other's MFMAs, same slab count) pay off once a
+  // workgroup has several chunks to stream; measured per layer in tools/wgrad_nw.py
+  const int nw = g_wgrad_nw ? g_wgrad_nw : ((p.cps >= 8 || (p.cps >= 4 && H * W >= 256)) ? 8 : 4);
   size_t lds = sizeof(float) * ((size_t)32 * WNn * 65 + (size_t)32 * WCn * (g.XS | 1)) + sizeof(int) * 64;
-  if (WNn * WCn < 4 && lds < sizeof(float) * 4 * 16 * 64) lds = sizeof(float) * 4 * 16 * 64;      // cross-wave reduce buffer
+  const size_t red = sizeof(float) * nw * 16 * 64;                                                // cross-wave reduce buffer
+  if (WNn * WCn < nw && lds < red) lds = red;
   const dim3 grid((Cout + 32 * WNn - 1) / (32 * WNn), (Cin + 32 * WCn - 1) / (32 * WCn), p.splits);
-  hipLaunchKernelGGL((conv_wgrad_mfma<T, WNn, WCn, NPB>), grid, dim3(256), lds, s, x, dy, part, bias_part, B, Cin, Cout, H, W, p.cps, p.nchunks, g);
+  if (nw == 8)
+    hipLaunchKernelGGL((conv_wgrad_mfma<T, WNn, WCn, NPB, 8>), grid, dim3(512), lds, s, x, dy, part, bias_part, B, Cin, Cout, H, W, p.cps, p.nchunks, g);
+  else
+    hipLaunchKernelGGL((conv_wgrad_mfma<T, WNn, WCn, NPB, 4>), grid, dim3(256), lds, s, x, dy, part, bias_part, B, Cin, Cout, H, W, p.cps, p.nchunks, g);
 }
 
 template <int T, int NPB>
@@ -808,7 +830,8 @@ using namespace afd;
 extern "C" {
 
 int afd_debug_conv_path(int mode) {
-  AFD_REQUIRE(mode >= 0 && mode <= 2, "afd_debug_conv_path: mode must be 0 (auto), 1 (big tile) or 2 (split-K tile)");
+  if (mode >= 32 && mode <= 34) { g_wgrad_nw = mode == 32 ? 4 : (mode == 33 ? 8 : 0); return AFD_OK; }   // wgrad waves: 4 / 8 / auto
+  AFD_REQUIRE(mode >= 0 && mode <= 2, "afd_debug_conv_path: mode must be 0 (auto), 1 (big tile), 2 (split-K tile) or 32..34 (wgrad waves 4/8/auto)");
   g_conv_path = mode;
   return AFD_OK;
 }
@@ -875,7 +898,7 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
     else if (p.npb == 5) launch_wgrad_roles<9, 5>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
     else launch_wgrad_roles<9, 8>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
     const long tot = n + (dbias ? Cout : 0);
-    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((tot + 31) / 32)), dim3(256), 0, s, part, dw, n, p.slabs, bp, dbias, dbias ? Cout : 0, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((tot + 31) / 32)), dim3(256), 0, s, part, dw, n, p.slabs, bp, dbias, dbias ? Cout : 0, accumulate, T);
     return check_launch("afd_conv_wgrad");
   } else {
     const dim3 grid((unsigned)(Cout * Cin));

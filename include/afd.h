@@ -106,7 +106,8 @@ int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, in
  * wgrad needs a workspace (split-K partial slabs + the (B,Cout) dbias partials); size from
  * afd_conv_wgrad_workspace_bytes. */
 /* test hook: 0 = choose the tile by workgroup count (default), 1 = always the 64x128 tile,
- * 2 = always the 32x64 in-workgroup split-K tile (when the shape allows it) */
+ * 2 = always the 32x64 in-workgroup split-K tile (when the shape allows it);
+ * 32 / 33 / 34 = wgrad workgroups of 4 waves / 8 waves / chosen per layer (default) */
 int afd_debug_conv_path(int mode);
 int afd_conv_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
                  int B, int Cin, int Cout, int H, int W, int ksize, int act, afd_stream_t stream);

@@ -198,15 +198,16 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("path", ["auto", "big", "splitk"])
+@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[5]}" for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(A, case, path):
     afdm, ops, dev = A
-    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2}[path])
+    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33}[path])
     try:
         _conv_case(ops, dev, case)
     finally:
         afdm.lib().afd_debug_conv_path(0)
+        afdm.lib().afd_debug_conv_path(34)
 
 
 def _conv_case(ops, dev, case):
@@ -248,6 +249,21 @@ def test_conv_full_size_matches_double_precision_sample(A):
     for b in (0, 1, 127, 255):
         ref = F.conv2d(x[b:b + 1].double(), w.double(), padding=1)
         assert rel_l2(y[b:b + 1], ref) < 5e-6
+
+
+def test_conv_wgrad_full_batch_matches_double_precision(A):
+    """BASELINE batch (256) for an encoder conv (32->32 @16x16, the 8-wave split-K plan): dw and db against fp64."""
+    _, ops, dev = A
+    g = _g(6)
+    x = torch.randn(256, 32, 16, 16, generator=g)
+    w = (torch.randn(32, 32, 3, 3, generator=g) / 17).requires_grad_(True)
+    b = torch.randn(32, generator=g).requires_grad_(True)
+    dy = torch.randn(256, 32, 16, 16, generator=g)
+    go = torch.autograd.grad(F.conv2d(x.double(), w.double(), b.double(), padding=1), (w, b), dy.double())
+    wd, bd = w.detach().to(dev).requires_grad_(True), b.detach().to(dev).requires_grad_(True)
+    gd = torch.autograd.grad(ops.conv(x.to(dev), wd, bd), (wd, bd), dy.to(dev))
+    assert rel_l2(gd[0].cpu(), go[0]) < 5e-6
+    assert rel_l2(gd[1].cpu(), go[1]) < 5e-6
 
 
 # ---------------------------------------------------------------------------------------------
