@@ -725,6 +725,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
 // ------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------
+// pw.hip: streaming kernel for the 1x1 projections
+bool pw_launch(const float* in, const float* w, const float* bias, const float* res, float* out, int B, int K, int N, int P,
+               int act, bool dgrad, hipStream_t s);
+void pw_set_mode(int m);
+
 static inline bool use_mfma(int K, int N, int H, int W, int PT) { return N >= 8 && tile_ok(H, W, PT); }   // K < 8 (inc.conv1) rides the ragged-chunk path
 
 static int g_conv_path = 0;       // 0 auto, 1 force the 64x128 tile, 2 force the split-K small tile (tests)
@@ -830,8 +835,9 @@ using namespace afd;
 extern "C" {
 
 int afd_debug_conv_path(int mode) {
+  if (mode >= 8 && mode <= 10) { pw_set_mode(mode - 8); return AFD_OK; }     // 1x1 streaming kernel: 8 = by rule (default), 9 = off, 10 = forced
   if (mode >= 32 && mode <= 34) { g_wgrad_nw = mode == 32 ? 4 : (mode == 33 ? 8 : 0); return AFD_OK; }   // wgrad waves: 4 / 8 / auto
-  AFD_REQUIRE(mode >= 0 && mode <= 2, "afd_debug_conv_path: mode must be 0 (auto), 1 (big tile), 2 (split-K tile) or 32..34 (wgrad waves 4/8/auto)");
+  AFD_REQUIRE(mode >= 0 && mode <= 2, "afd_debug_conv_path: mode must be 0 (auto), 1 (big tile), 2 (split-K tile), 8..10 (1x1 streaming auto/off/forced) or 32..34 (wgrad waves 4/8/auto)");
   g_conv_path = mode;
   return AFD_OK;
 }
@@ -842,6 +848,7 @@ int afd_conv_fwd(const float* x, const float* w, const float* bias, const float*
   AFD_REQUIRE(ksize == 1 || ksize == 3, "afd_conv_fwd: ksize %d not in {1,3}", ksize);
   AFD_REQUIRE(act == 0 || act == 1, "afd_conv_fwd: act must be 0 or 1");
   hipStream_t s = as_stream(st);
+  if (ksize == 1 && pw_launch(x, w, bias, res, y, B, Cin, Cout, H * W, act, false, s)) return check_launch("afd_conv_fwd");
   int rc = -1;
   if (use_mfma(Cin, Cout, H, W, 128))
     rc = ksize == 3 ? launch_mfma<9, false>(x, w, bias, res, y, B, Cin, Cout, H, W, act, s)
@@ -858,6 +865,7 @@ int afd_conv_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, i
   AFD_REQUIRE(dy && w && dx && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "afd_conv_dgrad: bad argument");
   AFD_REQUIRE(ksize == 1 || ksize == 3, "afd_conv_dgrad: ksize %d not in {1,3}", ksize);
   hipStream_t s = as_stream(st);
+  if (ksize == 1 && pw_launch(dy, w, nullptr, nullptr, dx, B, Cout, Cin, H * W, 0, true, s)) return check_launch("afd_conv_dgrad");
   int rc = -1;
   if (use_mfma(Cout, Cin, H, W, 128))     // reduction over Cout, output channels = Cin
     rc = ksize == 3 ? launch_mfma<9, true>(dy, w, nullptr, nullptr, dx, B, Cout, Cin, H, W, 0, s)

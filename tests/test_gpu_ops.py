@@ -195,19 +195,23 @@ CONV_CASES = [
     (2, 32, 96, 16, 16, 1, True, False),      # in_proj as 1x1
     (3, 64, 64, 8, 8, 1, True, True),         # out_proj + residual
     (2, 128, 128, 4, 4, 1, True, True),
+    (3, 64, 192, 16, 16, 1, True, False),     # in_proj at C=64: six 32-channel blocks per pixel tile
+    (5, 32, 32, 4, 4, 1, True, True),         # 16-pixel images: a 32-pixel tile spans two of them, ragged last tile
+    (2, 24, 40, 8, 8, 1, True, False),        # K, N not multiples of 32
 ]
 
 
-@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8"])
+@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[5]}" for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(A, case, path):
     afdm, ops, dev = A
-    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33}[path])
+    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10}[path])
     try:
         _conv_case(ops, dev, case)
     finally:
         afdm.lib().afd_debug_conv_path(0)
         afdm.lib().afd_debug_conv_path(34)
+        afdm.lib().afd_debug_conv_path(8)
 
 
 def _conv_case(ops, dev, case):
@@ -249,6 +253,26 @@ def test_conv_full_size_matches_double_precision_sample(A):
     for b in (0, 1, 127, 255):
         ref = F.conv2d(x[b:b + 1].double(), w.double(), padding=1)
         assert rel_l2(y[b:b + 1], ref) < 5e-6
+
+
+def test_pointwise_full_batch_matches_double_precision(A):
+    """BASELINE batch for sa6's in_proj (32->96 @32x32, B=256: the streaming kernel by the default rule) fwd + dgrad,
+    spot-checked on 4 images against fp64."""
+    _, ops, dev = A
+    g = _g(8)
+    x = torch.randn(256, 32, 32, 32, generator=g)
+    w = torch.randn(96, 32, 1, 1, generator=g) / 6
+    b = torch.randn(96, generator=g)
+    dy = torch.randn(256, 96, 32, 32, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    yd = ops.conv(xd, w.to(dev), b.to(dev))
+    (dxd,) = torch.autograd.grad(yd, xd, dy.to(dev))
+    for i in (0, 1, 130, 255):
+        xi = x[i:i + 1].double().requires_grad_(True)
+        yi = F.conv2d(xi, w.double(), b.double())
+        (dxi,) = torch.autograd.grad(yi, xi, dy[i:i + 1].double())
+        assert rel_l2(yd[i:i + 1].detach().cpu(), yi.detach()) < 5e-6
+        assert rel_l2(dxd[i:i + 1].cpu(), dxi) < 5e-6
 
 
 def test_conv_wgrad_full_batch_matches_double_precision(A):
