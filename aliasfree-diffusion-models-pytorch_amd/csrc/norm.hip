@@ -134,6 +134,23 @@ __global__ __launch_bounds__(256) void gn_bwd_plane(const float* __restrict__ x,
   }
 }
 
+// dgamma[c] (+)= sum_b part[b][0][c], dbeta[c] (+)= sum_b part[b][1][c], folded into the tail of the kernel that runs
+// after the partials exist: block `blk` of `nblk` takes channels blk, blk+nblk, ... (fixed order: deterministic).
+// Saves one tiny latency-bound launch per normalisation site (44 per training step).
+__device__ __forceinline__ void fold_param_grads(const float* __restrict__ part, int B, int C, float* __restrict__ dgamma,
+                                                 float* __restrict__ dbeta, int accumulate, float* red, long blk, long nblk) {
+  for (long c = blk; c < C; c += nblk) {
+    float a = 0.f, b2 = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) { a += part[(2L * b) * C + c]; b2 += part[(2L * b + 1) * C + c]; }
+    a = block_sum(a, red);
+    b2 = block_sum(b2, red);
+    if (threadIdx.x == 0) {
+      dgamma[c] = accumulate ? dgamma[c] + a : a;
+      dbeta[c] = accumulate ? dbeta[c] + b2 : b2;
+    }
+  }
+}
+
 // dx = rstd * (gamma*dz - m1 - xhat*m2), with m1 = mean_sample(gamma*dz), m2 = mean_sample(gamma*dz*xhat).
 // grid = (slices of the sample, B): every block first contracts the (2, C) partials of its sample with gamma
 // (C <= a few hundred values: cheaper than a separate launch), then applies its slice.
@@ -141,7 +158,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ x,
                                                     const float* __restrict__ stats, const float* __restrict__ part,
                                                     int C, int HW, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, const float* __restrict__ res, int act,
-                                                    float* __restrict__ dx) {
+                                                    float* __restrict__ dx, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, int accumulate) {
   __shared__ float red[16];
   const long b = blockIdx.y;
   float a = 0.f, c2 = 0.f;
@@ -165,6 +183,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ x,
     const float dz = gn_dz(xh, dy[gi], g, beta[c], res ? res[gi] : 0.f, act);
     dx[gi] = rstd * (g * dz - m1 - xh * m2);
   }
+  if (dgamma) fold_param_grads(part, gridDim.y, C, dgamma, dbeta, accumulate, red, blockIdx.y * gridDim.x + blockIdx.x, (long)gridDim.x * gridDim.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -214,47 +233,57 @@ __global__ __launch_bounds__(256) void ln_c_fwd_reg(const float* __restrict__ x,
 
 __global__ __launch_bounds__(256) void ln_c_bwd_dx(const float* __restrict__ x, const float* __restrict__ dy,
                                                    const float* __restrict__ stats, int C, int HW, long pixels,
-                                                   const float* __restrict__ gamma, float* __restrict__ dx) {
+                                                   const float* __restrict__ gamma, float* __restrict__ dx,
+                                                   const float* __restrict__ part, int B, float* __restrict__ dgamma,
+                                                   float* __restrict__ dbeta, int accumulate) {
+  __shared__ float red[16];
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= pixels) return;
-  const long b = p / HW; const int l = p % HW;
-  const long off = b * (long)C * HW + l;
-  const float mean = stats[2 * p], rstd = stats[2 * p + 1];
-  float s1 = 0.f, s2 = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float g = gamma[c] * dy[off + (long)c * HW];
-    s1 += g; s2 += g * ((x[off + (long)c * HW] - mean) * rstd);
+  if (p < pixels) {
+    const long b = p / HW; const int l = p % HW;
+    const long off = b * (long)C * HW + l;
+    const float mean = stats[2 * p], rstd = stats[2 * p + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float g = gamma[c] * dy[off + (long)c * HW];
+      s1 += g; s2 += g * ((x[off + (long)c * HW] - mean) * rstd);
+    }
+    const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+    for (int c = 0; c < C; ++c) {
+      const float xh = (x[off + (long)c * HW] - mean) * rstd;
+      dx[off + (long)c * HW] = rstd * (gamma[c] * dy[off + (long)c * HW] - m1 - xh * m2);
+    }
   }
-  const float m1 = s1 / (float)C, m2 = s2 / (float)C;
-  for (int c = 0; c < C; ++c) {
-    const float xh = (x[off + (long)c * HW] - mean) * rstd;
-    dx[off + (long)c * HW] = rstd * (gamma[c] * dy[off + (long)c * HW] - m1 - xh * m2);
-  }
+  if (dgamma) fold_param_grads(part, B, C, dgamma, dbeta, accumulate, red, blockIdx.x, gridDim.x);
 }
 
 // register form: gamma*dy is kept in registers, x is read twice (second read hits L2)
 template <int C>
 __global__ __launch_bounds__(256) void ln_c_bwd_dx_reg(const float* __restrict__ x, const float* __restrict__ dy,
                                                        const float* __restrict__ stats, int HW, long pixels,
-                                                       const float* __restrict__ gamma, float* __restrict__ dx) {
+                                                       const float* __restrict__ gamma, float* __restrict__ dx,
+                                                       const float* __restrict__ part, int B, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, int accumulate) {
+  __shared__ float red[16];
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= pixels) return;
-  const long b = p / HW; const int l = p % HW;
-  const long off = b * (long)C * HW + l;
-  const float mean = stats[2 * p], rstd = stats[2 * p + 1];
-  float g[C];
-  float s1 = 0.f, s2 = 0.f;
+  if (p < pixels) {
+    const long b = p / HW; const int l = p % HW;
+    const long off = b * (long)C * HW + l;
+    const float mean = stats[2 * p], rstd = stats[2 * p + 1];
+    float g[C];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    g[c] = gamma[c] * dy[off + (long)c * HW];
-    s1 += g[c]; s2 += g[c] * ((x[off + (long)c * HW] - mean) * rstd);
-  }
-  const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+    for (int c = 0; c < C; ++c) {
+      g[c] = gamma[c] * dy[off + (long)c * HW];
+      s1 += g[c]; s2 += g[c] * ((x[off + (long)c * HW] - mean) * rstd);
+    }
+    const float m1 = s1 / (float)C, m2 = s2 / (float)C;
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float xh = (x[off + (long)c * HW] - mean) * rstd;
-    dx[off + (long)c * HW] = rstd * (g[c] - m1 - xh * m2);
+    for (int c = 0; c < C; ++c) {
+      const float xh = (x[off + (long)c * HW] - mean) * rstd;
+      dx[off + (long)c * HW] = rstd * (g[c] - m1 - xh * m2);
+    }
   }
+  if (dgamma) fold_param_grads(part, B, C, dgamma, dbeta, accumulate, red, blockIdx.x, gridDim.x);
 }
 
 // one wave per (b, c) plane: part[b][0][c] = sum_l dy*xhat, part[b][1][c] = sum_l dy
@@ -315,8 +344,10 @@ int afd_groupnorm1_fwd(const float* x, float* y, float* stats_out, int B, int C,
 
 int afd_groupnorm1_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
                        const float* gamma, const float* beta, const float* res, int act,
-                       float* dx, float* dres, float* part, float* demb, int have_partials, afd_stream_t st) {
+                       float* dx, float* dres, float* part, float* demb, int have_partials,
+                       float* dgamma, float* dbeta, int accumulate, afd_stream_t st) {
   AFD_REQUIRE(x && dy && stats && gamma && beta && dx && part && B > 0 && C > 0 && HW > 0, "afd_groupnorm1_bwd: bad argument");
+  AFD_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "afd_groupnorm1_bwd: dgamma and dbeta come together");
   AFD_REQUIRE(act == 0 || act == 1, "afd_groupnorm1_bwd: act must be 0 or 1");
   AFD_REQUIRE(!have_partials || (!dres && !demb && act == 0 && !res), "afd_groupnorm1_bwd: have_partials only for the plain form");
   hipStream_t s = as_stream(st);
@@ -328,7 +359,7 @@ int afd_groupnorm1_bwd(const float* x, const float* dy, const float* stats, int 
   if (slices < 1) slices = 1;
   if (slices > 64) slices = 64;
   AFD_REQUIRE(B <= 65535, "afd_groupnorm1_bwd: batch too large for the grid");
-  hipLaunchKernelGGL(gn_bwd_apply, dim3(slices, B), dim3(256), 0, s, x, dy, stats, part, C, HW, gamma, beta, res, act, dx);
+  hipLaunchKernelGGL(gn_bwd_apply, dim3(slices, B), dim3(256), 0, s, x, dy, stats, part, C, HW, gamma, beta, res, act, dx, dgamma, dbeta, accumulate);
   return check_launch("afd_groupnorm1_bwd");
 }
 
@@ -348,18 +379,21 @@ int afd_layernorm_c_fwd(const float* x, float* y, float* stats_out, int B, int C
 }
 
 int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
-                        const float* gamma, float* dx, float* part, afd_stream_t st) {
+                        const float* gamma, float* dx, float* part, float* dgamma, float* dbeta, int accumulate,
+                        afd_stream_t st) {
   AFD_REQUIRE(x && dy && stats && gamma && dx && part && B > 0 && C > 0 && HW > 0, "afd_layernorm_c_bwd: bad argument");
+  AFD_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "afd_layernorm_c_bwd: dgamma and dbeta come together");
   hipStream_t s = as_stream(st);
   const long pixels = (long)B * HW, planes = (long)B * C;
   const dim3 grid((unsigned)((pixels + 255) / 256));
-  switch (C) {
-    case 32:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<32>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx); break;
-    case 64:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<64>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx); break;
-    case 128: hipLaunchKernelGGL(ln_c_bwd_dx_reg<128>, grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx); break;
-    default:  hipLaunchKernelGGL(ln_c_bwd_dx, grid, dim3(256), 0, s, x, dy, stats, C, HW, pixels, gamma, dx);
-  }
+  // plane partials first: the dx kernel's tail folds them into dgamma / dbeta
   hipLaunchKernelGGL(ln_c_bwd_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, x, dy, stats, C, HW, planes, part);
+  switch (C) {
+    case 32:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<32>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate); break;
+    case 64:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<64>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate); break;
+    case 128: hipLaunchKernelGGL(ln_c_bwd_dx_reg<128>, grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate); break;
+    default:  hipLaunchKernelGGL(ln_c_bwd_dx, grid, dim3(256), 0, s, x, dy, stats, C, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate);
+  }
   return check_launch("afd_layernorm_c_bwd");
 }
 

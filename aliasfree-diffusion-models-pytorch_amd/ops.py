@@ -159,16 +159,13 @@ def _direct(*params):
     return True
 
 
-def _gn_param_grads(part, B, C, gamma=None, beta=None):
-    """(B,2,C) partials -> dgamma (C,), dbeta (C,) via the deterministic column sum."""
-    if gamma is not None and _direct(gamma, beta):
-        L = lib()
-        # rows of `part` are 2C wide: column block [0,C) -> dgamma, [C,2C) -> dbeta; accumulate in place
-        L.afd_colsum2(_p(part), _p(gamma.grad), _p(beta.grad), B, C, 1, _stream())
-        return None, None
-    out = torch.empty(2, C, device=part.device, dtype=torch.float32)
-    lib().afd_colsum(_p(part), _p(out), B, 2 * C, 0, _stream())
-    return out[0], out[1]
+def _gn_param_targets(C, gamma, beta, device):
+    """Where a normalisation backward's tail writes dgamma / dbeta: straight into the parameters' .grad (in-place
+    mode, accumulate = 1) or into a fresh (2, C) pair returned to autograd.  -> (dg, db, accumulate, returned pair)"""
+    if gamma is not None and beta is not None and _direct(gamma, beta):
+        return gamma.grad, beta.grad, 1, (None, None)
+    out = torch.empty(2, C, device=device, dtype=torch.float32)
+    return out[0], out[1], 0, (out[0], out[1])
 
 
 class GroupNorm1(torch.autograd.Function):
@@ -198,9 +195,10 @@ class GroupNorm1(torch.autograd.Function):
             dres = dy if ctx.act == 0 else torch.empty_like(x)      # act == 0: d(res) is dy itself
         part = torch.empty(B * C * 2, device=x.device, dtype=torch.float32)
         demb = torch.empty(B, C, device=x.device, dtype=torch.float32) if ctx.has_emb else None
+        dg, db, acc, (dgamma, dbeta) = _gn_param_targets(C, gamma, beta, x.device)
         lib().afd_groupnorm1_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(beta), _p(res), ctx.act,
-                                 _p(dx), _p(dres) if (res is not None and ctx.act == 1) else None, _p(part), _p(demb), 0, _stream())
-        dgamma, dbeta = _gn_param_grads(part, B, C, gamma, beta)
+                                 _p(dx), _p(dres) if (res is not None and ctx.act == 1) else None, _p(part), _p(demb), 0,
+                                 _p(dg), _p(db), acc, _stream())
         return dx, dgamma, dbeta, dres, demb, None
 
 
@@ -240,9 +238,9 @@ class GroupNormFiltAct(torch.autograd.Function):
         L.afd_filt_act_bwd(_p(x), _p(dy), _p(dv), B, C, H, W, _p(stats), _p(gamma), _p(beta), _p(res),
                            ctx.tu.ptr, ctx.td.ptr, ctx.tu.N, _p(ws), _p(part) if fused else None, _stream())
         dx = torch.empty_like(x)
+        dg, db, acc, (dgamma, dbeta) = _gn_param_targets(C, gamma, beta, x.device)
         L.afd_groupnorm1_bwd(_p(x), _p(dv), _p(stats), B, C, H * W, _p(gamma), _p(beta), None, 0,
-                             _p(dx), None, _p(part), None, 1 if fused else 0, _stream())
-        dgamma, dbeta = _gn_param_grads(part, B, C, gamma, beta)
+                             _p(dx), None, _p(part), None, 1 if fused else 0, _p(dg), _p(db), acc, _stream())
         return dx, dgamma, dbeta, (dv if res is not None else None), None, None
 
 
@@ -337,8 +335,9 @@ class LayerNormC(torch.autograd.Function):
         dy = _c(dy)
         dx = torch.empty_like(x)
         part = torch.empty(B, 2, C, device=x.device, dtype=torch.float32)
-        lib().afd_layernorm_c_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(dx), _p(part), _stream())
-        dgamma, dbeta = _gn_param_grads(part, B, C, gamma, ctx.beta_param)
+        dg, db, acc, (dgamma, dbeta) = _gn_param_targets(C, gamma, ctx.beta_param, x.device)
+        lib().afd_layernorm_c_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(dx), _p(part), _p(dg), _p(db), acc,
+                                  _stream())
         return dx, dgamma, dbeta
 
 

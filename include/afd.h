@@ -83,14 +83,17 @@ int afd_filt_act_bwd(const float* x, const float* dy, float* dv, int B, int C, i
  *   emb  (B,C) or NULL     : time-embedding add of Down/Up (:218-219, :244-245).
  * bwd: given dy (= dL/dy) recomputes the chain; writes dx, dres (may be NULL), and per-sample
  *   partials laid out (B, 2, C): [b][0][c] = sum dz*xhat (-> dgamma), [b][1][c] = sum dz (-> dbeta), which
- *   afd_colsum reduces over b into a (2, C) row pair.  The partial buffer holds B*C*2 floats.  demb = sum_hw dy is (B,C). */
+ *   the kernel's tail reduces over b into dgamma / dbeta (both NULL: the caller reduces the partials itself, e.g. with
+ *   afd_colsum; accumulate = 1 adds into them, as autograd's .grad accumulation would).  The partial buffer holds
+ *   B*C*2 floats.  demb = sum_hw dy is (B,C). */
 int afd_groupnorm1_fwd(const float* x, float* y, float* stats_out, int B, int C, int HW, float eps,
                        const float* gamma, const float* beta, const float* res, int act, const float* emb,
                        afd_stream_t stream);
 int afd_groupnorm1_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
                        const float* gamma, const float* beta, const float* res, int act,
                        float* dx, float* dres, float* dgamma_dbeta_partial /* B*C*2 floats, (B,2,C) */, float* demb /* (B,C) or NULL */,
-                       int have_partials /* 1: the partials were already produced by afd_filt_act_bwd */, afd_stream_t stream);
+                       int have_partials /* 1: the partials were already produced by afd_filt_act_bwd */,
+                       float* dgamma /* (C) or NULL */, float* dbeta /* (C) or NULL */, int accumulate, afd_stream_t stream);
 /* out[j] (+)= sum_i in[i*cols + j], i < rows (deterministic tree; accumulate != 0 adds into out) */
 int afd_colsum(const float* in, float* out, int rows, int cols, int accumulate, afd_stream_t stream);
 /* same with an explicit row stride (elements): sums a column block of a wider matrix */
@@ -125,6 +128,7 @@ int afd_layernorm_c_fwd(const float* x, float* y, float* stats_out, int B, int C
                         const float* gamma, const float* beta, afd_stream_t stream);
 int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
                         const float* gamma, float* dx, float* dgamma_dbeta_partial /* (B,2,C) */,
+                        float* dgamma /* (C) or NULL */, float* dbeta /* (C) or NULL */, int accumulate,
                         afd_stream_t stream);
 
 /* ---- F10: multi-head self-attention core (softmax(QK^T/sqrt(d))V), flash-style ------------------
