@@ -729,6 +729,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
 bool pw_launch(const float* in, const float* w, const float* bias, const float* res, float* out, int B, int K, int N, int P,
                int act, bool dgrad, hipStream_t s);
 void pw_set_mode(int m);
+// wino.hip: Winograd F(2x2,3x3) forward / dgrad
+int wino_plan(int B, int K, int N, int H, int W);
+bool wino_conv(const float* x, const float* w, const float* bias, const float* res, float* y, float* U, int B, int K, int N, int H,
+               int W, int act, bool dgrad, bool weights_ready, hipStream_t s);
+void wino_set_mode(int m);
+void wino_set_dbg(int d);
 
 static inline bool use_mfma(int K, int N, int H, int W, int PT) { return N >= 8 && tile_ok(H, W, PT); }   // K < 8 (inc.conv1) rides the ragged-chunk path
 
@@ -836,8 +842,10 @@ extern "C" {
 
 int afd_debug_conv_path(int mode) {
   if (mode >= 8 && mode <= 10) { pw_set_mode(mode - 8); return AFD_OK; }     // 1x1 streaming kernel: 8 = by rule (default), 9 = off, 10 = forced
+  if (mode >= 1000 && mode < 1064) { wino_set_dbg(mode - 1000); return AFD_OK; }   // ablation switches (tools/wino_abl.py)
+  if (mode >= 64 && mode <= 69) { wino_set_mode(mode - 64); return AFD_OK; }   // Winograd 3x3: 64 = by rule (default), 65 = off, 66..69 = forced, workgroups of 64x64 / 32x64 / 64x32 / 32x32 (channels x tiles)
   if (mode >= 32 && mode <= 34) { g_wgrad_nw = mode == 32 ? 4 : (mode == 33 ? 8 : 0); return AFD_OK; }   // wgrad waves: 4 / 8 / auto
-  AFD_REQUIRE(mode >= 0 && mode <= 2, "afd_debug_conv_path: mode must be 0 (auto), 1 (big tile), 2 (split-K tile), 8..10 (1x1 streaming auto/off/forced) or 32..34 (wgrad waves 4/8/auto)");
+  AFD_REQUIRE(mode >= 0 && mode <= 2, "afd_debug_conv_path: mode must be 0 (auto), 1 (big tile), 2 (split-K tile), 8..10 (1x1 streaming auto/off/forced), 32..34 (wgrad waves 4/8/auto) or 64..67 (Winograd auto/off/forced 64/forced 32)");
   g_conv_path = mode;
   return AFD_OK;
 }
@@ -876,6 +884,29 @@ int afd_conv_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, i
     else hipLaunchKernelGGL(conv_direct_dgrad<1>, dim3(gs_grid(total)), dim3(256), 0, s, dy, w, dx, Cin, Cout, H, W, total);
   }
   return check_launch("afd_conv_dgrad");
+}
+
+size_t afd_conv3x3_wino_workspace_bytes(int B, int Cin, int Cout, int H, int W, int dgrad) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+  return wino_plan(B, K, N, H, W) ? sizeof(float) * 16 * (size_t)Cin * Cout : 0;
+}
+
+int afd_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
+                         int B, int Cin, int Cout, int H, int W, int act, void* workspace, int weights_ready, afd_stream_t st) {
+  AFD_REQUIRE(x && w && y && workspace && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "afd_conv3x3_wino_fwd: bad argument");
+  AFD_REQUIRE(act == 0 || act == 1, "afd_conv3x3_wino_fwd: act must be 0 or 1");
+  AFD_REQUIRE(wino_conv(x, w, bias, res, y, static_cast<float*>(workspace), B, Cin, Cout, H, W, act, false, weights_ready != 0, as_stream(st)),
+              "afd_conv3x3_wino_fwd: shape (%d,%d->%d,%dx%d) is not covered (afd_conv3x3_wino_workspace_bytes returns 0 for it)", B, Cin, Cout, H, W);
+  return check_launch("afd_conv3x3_wino_fwd");
+}
+
+int afd_conv3x3_wino_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H, int W, void* workspace,
+                           int weights_ready, afd_stream_t st) {
+  AFD_REQUIRE(dy && w && dx && workspace && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "afd_conv3x3_wino_dgrad: bad argument");
+  AFD_REQUIRE(wino_conv(dy, w, nullptr, nullptr, dx, static_cast<float*>(workspace), B, Cout, Cin, H, W, 0, true, weights_ready != 0, as_stream(st)),
+              "afd_conv3x3_wino_dgrad: shape (%d,%d->%d,%dx%d) is not covered", B, Cin, Cout, H, W);
+  return check_launch("afd_conv3x3_wino_dgrad");
 }
 
 size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ksize) {

@@ -1,0 +1,306 @@
+// wino.hip -- F5: 3x3 (pad 1) convolution forward / dgrad by Winograd F(2x2, 3x3) on the exact-fp32
+// matrix cores.  Y = A^T [ sum_k (G g G^T) .* (B^T d B) ] A : every 2x2 output tile costs 16 multiplies per
+// (cin, cout) pair instead of 36, so the MFMA work of a 3x3 layer drops 2.25x; everything stays fp32
+// (inputs, products, accumulation), only the association of the sums differs from the direct form.
+//
+//   wino_weights   U[k/8][xi][n][8] = (G g G^T)[xi]   (xi = 4i + j; the 8 channels of a chunk stored in MFMA
+//                  fragment order), once per call; for dgrad the taps are flipped and the channel roles swapped,
+//                  so ONE main kernel serves both passes.
+//   conv_wino      a workgroup owns BN output channels x 64 tiles (= 256 output pixels).  Per chunk of 8 input
+//                  channels: the haloed input rows and the U chunk are staged global -> registers -> LDS (the
+//                  next chunk's loads are in flight during the multiplies); each lane transforms the two
+//                  (tile, channel) 4x4 patches that ARE its B operands (2 x 32 adds, V never exists in memory),
+//                  then the wave multiplies its 32 channels x 16 tiles for all 16 xi with
+//                  v_mfma_f32_16x16x4_f32 (128 accumulator registers).
+//                  The 16 xi of one (channel, tile) sit in ONE lane, so the output transform A^T M A is
+//                  register arithmetic and the 2x2 results leave as float2 stores.
+#include "common.h"
+
+namespace afd {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// geometry of an NT-tile workgroup on a square S x S map: either TROWS rows of tiles of ONE image (NT <= tiles per
+// image) or TI whole images.  The haloed input rows of the group live in LDS as [channel][TI][RROWS][Wp].
+template <int S, int NT> struct WGeo {
+  static constexpr int W = S, TPR = S / 2, TPI = TPR * TPR;                 // tiles per row / per image
+  static constexpr int TI = NT <= TPI ? 1 : NT / TPI;                       // images per group
+  static constexpr int TROWS = NT <= TPI ? NT / TPR : TPR;                  // tile rows per image in the group
+  static constexpr int GPI = NT <= TPI ? TPI / NT : 1;                      // groups per image
+  static constexpr int PXR = 2 * TROWS, Wp = S + 2, IMG = (PXR + 2) * Wp, RS = TI * IMG;
+  static constexpr int RSP = RS + ((32 - RS % 64) + 64) % 64;               // channel stride = 32 mod 64 banks: the two channels of a b64 lane group never collide
+  static_assert(NT % TPR == 0 && (NT <= TPI ? TPI % NT == 0 : NT % TPI == 0), "tile group must be whole tile rows or whole images");
+};
+
+__device__ __forceinline__ int kperm8(int k) { return 2 * (k & 3) + (k >> 2); }   // LDS slot of channel k of a chunk: lane quarter q reads k = q, q + 4 as one b64
+
+// U[(k>>3)][xi][n][kperm8(k&7)] = (G g G^T)[xi] with g = w[n][k] (forward) or the flipped w[k][n] (dgrad)
+__global__ __launch_bounds__(256) void wino_weights(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout, int dgrad) {
+  const int Nn = dgrad ? Cin : Cout, Kk = dgrad ? Cout : Cin;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Nn * Kk) return;
+  const int k = idx % Kk, n = idx / Kk;
+  float g[9];
+  if (!dgrad) {
+    const float* p = w + ((long)n * Cin + k) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = p[t];
+  } else {
+    const float* p = w + ((long)k * Cin + n) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = p[8 - t];
+  }
+  // t = G g  (4x3), u = t G^T (4x4);  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+  float t[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float g0 = g[c], g1 = g[3 + c], g2 = g[6 + c];
+    t[0][c] = g0;
+    t[1][c] = 0.5f * (g0 + g1 + g2);
+    t[2][c] = 0.5f * (g0 - g1 + g2);
+    t[3][c] = g2;
+  }
+  float* o = U + ((long)(k >> 3) * 16 * Nn + n) * 8 + kperm8(k & 7);
+  const long xs = (long)Nn * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = t[i][0], b = t[i][1], c = t[i][2];
+    o[(4 * i + 0) * xs] = a;
+    o[(4 * i + 1) * xs] = 0.5f * (a + b + c);
+    o[(4 * i + 2) * xs] = 0.5f * (a - b + c);
+    o[(4 * i + 3) * xs] = c;
+  }
+}
+
+template <int GEO, int BN, int NT>
+__global__ __launch_bounds__(BN * NT / 8, BN * NT == 4096 ? 1 : 2) void conv_wino(const float* __restrict__ x, const float* __restrict__ U,
+                                                    const float* __restrict__ bias, const float* __restrict__ res,
+                                                    float* __restrict__ y, int B, int K, int N, int act) {
+  using G = WGeo<GEO, NT>;
+  constexpr int KC = 8, SU = 10, NTH = BN * NT / 8;                        // one wave per 32 channels x 16 tiles
+  constexpr int W = G::W, H = G::W, HW = W * W, Wp = G::Wp, IMG = G::IMG, RS = G::RS, RSP = G::RSP;
+  constexpr int NPOS = (RS + NTH - 1) / NTH;         // raw positions per thread
+  constexpr int NUV = 16 * BN * 2 / NTH;             // float4 pieces of the U chunk per thread
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Us = smem;                                  // [16][BN][SU]
+  float* Rs = Us + 16 * BN * SU;                     // [KC][RSP]   haloed input rows
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n0 = blockIdx.x * BN;
+  const int tg = blockIdx.y;
+  const int b0 = (G::TI == 1) ? tg / G::GPI : tg * G::TI;
+  const int row0 = (G::TI == 1) ? (tg % G::GPI) * G::PXR : 0;
+
+  // ---- staging plans (chunk-invariant)
+  unsigned rsrc[NPOS]; bool rval[NPOS]; int rpos[NPOS];
+#pragma unroll
+  for (int e = 0; e < NPOS; ++e) {
+    const int pos = tid + NTH * e;
+    rpos[e] = pos;
+    bool ok = false; unsigned src = 0;
+    if (pos < RS) {
+      const int ti = pos / IMG, rem = pos % IMG;
+      const int yy = row0 + rem / Wp - 1, xx = rem % Wp - 1, b = b0 + ti;
+      ok = b < B && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      if (ok) src = (unsigned)(b * K) * (unsigned)HW + (unsigned)(yy * W + xx);
+    }
+    rval[e] = ok; rsrc[e] = src;
+  }
+  // U pieces: piece e of a thread is the same (row, half) XSTEP xi-planes further on, so one source offset and one
+  // LDS offset serve all of them (the per-piece part is a scalar / an immediate)
+  constexpr int XSTEP = NTH / (2 * BN);
+  static_assert(NTH % (2 * BN) == 0 && XSTEP * NUV == 16, "U chunk must split into whole xi planes per pass");
+  const int u_h = tid & 1, u_n = (tid >> 1) % BN, u_xi = tid / (2 * BN);
+  const unsigned usrc0 = (unsigned)((u_xi * N + n0 + u_n) * 8 + 4 * u_h);
+  const int udst0 = (u_xi * BN + u_n) * SU + 4 * u_h;
+  const long ustep = (long)XSTEP * N * 8;
+  // transform unit(s): tile tt = tid % NT; channel kq (and kq + 4 when a thread owns two)
+  // ---- wave roles: 32 channels x 16 tiles, all 16 xi.  Lane (li, lq): A rows wn*32 + {li, 16 + li}, tile wt*16 + li,
+  // channels lq and lq + 4 of the chunk (the two k-steps of v_mfma_f32_16x16x4_f32)
+  const int wn = wv % (BN / 32), wt = wv / (BN / 32);
+  const int li = lane & 15, lq = lane >> 4;
+  const int tt = wt * 16 + li;
+  const int poff = (tt / (G::TROWS * G::TPR)) * IMG + 2 * ((tt / G::TPR) % G::TROWS) * Wp + 2 * (tt % G::TPR);
+
+  float rreg[NPOS][KC];
+  f32x4 ureg[NUV];
+  auto fetch = [&](int c) {
+    const float* __restrict__ xk = x + (long)c * KC * HW;
+    const float* __restrict__ uk = U + (long)c * 16 * N * 8;
+#pragma unroll
+    for (int e = 0; e < NUV; ++e) ureg[e] = *reinterpret_cast<const f32x4*>(uk + e * ustep + usrc0);
+#pragma unroll
+    for (int e = 0; e < NPOS; ++e)
+      if (rpos[e] < RS) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) rreg[e][kc] = xk[rsrc[e] + (unsigned)(kc * HW)];
+      }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int e = 0; e < NUV; ++e) {
+      float2* d = reinterpret_cast<float2*>(Us + udst0 + e * (XSTEP * BN * SU));
+      d[0] = make_float2(ureg[e][0], ureg[e][1]);
+      d[1] = make_float2(ureg[e][2], ureg[e][3]);
+    }
+#pragma unroll
+    for (int e = 0; e < NPOS; ++e)
+      if (rpos[e] < RS) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) Rs[kc * RSP + rpos[e]] = rval[e] ? rreg[e][kc] : 0.f;
+      }
+  };
+  // V = B^T d B for one 4x4 patch; B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
+  auto patch = [&](int k, float (&v)[16]) {
+    const float* r = Rs + k * RSP + poff;
+    float d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float2 lo = *reinterpret_cast<const float2*>(r + a * Wp);
+      const float2 hi = *reinterpret_cast<const float2*>(r + a * Wp + 2);
+      d[a][0] = lo.x; d[a][1] = lo.y; d[a][2] = hi.x; d[a][3] = hi.y;
+    }
+    float w[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w[0][j] = d[0][j] - d[2][j];
+      w[1][j] = d[1][j] + d[2][j];
+      w[2][j] = d[2][j] - d[1][j];
+      w[3][j] = d[1][j] - d[3][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[4 * i + 0] = w[i][0] - w[i][2];
+      v[4 * i + 1] = w[i][1] + w[i][2];
+      v[4 * i + 2] = w[i][2] - w[i][1];
+      v[4 * i + 3] = w[i][1] - w[i][3];
+    }
+  };
+  const float* ap = Us + (wn * 32 + li) * SU + 2 * lq;
+  auto lds_pair = [&](const float* p) {               // one ds_read2_b64: the b64 at p and the one 16 rows further on
+    const float2 lo = *reinterpret_cast<const float2*>(p), hi = *reinterpret_cast<const float2*>(p + 16 * SU);
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+  };
+
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[xi][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = K / KC;
+  fetch(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();                                  // the previous chunk's multiplies are done with Us / Rs
+    commit();
+    if (c + 1 < nchunks) fetch(c + 1);                // in flight during the transform and the multiplies
+    __syncthreads();
+    // A fragments run one xi ahead of the multiplies (the first pair is in flight under the transform)
+    float4 an = lds_pair(ap);
+    // the wave's own B operands: V = B^T d B of its 16 tiles x 8 channels, straight into registers (the waves that
+    // share these tiles repeat the 32 adds; no V image in LDS, no third barrier)
+    float v0[16], v1[16];
+    patch(lq, v0);
+    patch(lq + 4, v1);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+      const float4 a = an;                            // {a0.x, a0.y, a1.x, a1.y}: rows li and 16 + li, channels lq and lq + 4
+      if (xi < 15) an = lds_pair(ap + (xi + 1) * BN * SU);
+      __builtin_amdgcn_sched_barrier(0);              // the next pair's read stays ABOVE these multiplies
+      acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, v0[xi], acc[xi][0], 0, 0, 0);
+      acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, v0[xi], acc[xi][1], 0, 0, 0);
+      acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, v1[xi], acc[xi][0], 0, 0, 0);
+      acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, v1[xi], acc[xi][1], 0, 0, 0);
+    }
+  }
+
+  // ---- output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) and the epilogue.  Lane: tile wt*16 + li,
+  // channels n0 + wn*32 + 16*h + 4*lq + r.
+  const int ot = tt;
+  const int o_ti = ot / (G::TROWS * G::TPR), o_ty = (ot / G::TPR) % G::TROWS, o_tx = ot % G::TPR;
+  const int ob = b0 + o_ti;
+  if (ob >= B) return;
+  const int opix = (row0 + 2 * o_ty) * W + 2 * o_tx;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * 32 + 16 * h + 4 * lq + r;
+      float tcol[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float m0 = acc[4 * i + 0][h][r], m1 = acc[4 * i + 1][h][r], m2 = acc[4 * i + 2][h][r], m3 = acc[4 * i + 3][h][r];
+        tcol[i][0] = (m0 + m1) + m2;
+        tcol[i][1] = (m1 - m2) - m3;
+      }
+      float y00 = (tcol[0][0] + tcol[1][0]) + tcol[2][0], y01 = (tcol[0][1] + tcol[1][1]) + tcol[2][1];
+      float y10 = (tcol[1][0] - tcol[2][0]) - tcol[3][0], y11 = (tcol[1][1] - tcol[2][1]) - tcol[3][1];
+      const long idx = ((long)ob * N + n) * HW + opix;
+      if (bias) { const float bb = bias[n]; y00 += bb; y01 += bb; y10 += bb; y11 += bb; }
+      if (act == 1) { y00 = gelu_erf(y00); y01 = gelu_erf(y01); y10 = gelu_erf(y10); y11 = gelu_erf(y11); }
+      if (res) {
+        const float2 r0 = *reinterpret_cast<const float2*>(res + idx), r1 = *reinterpret_cast<const float2*>(res + idx + W);
+        y00 += r0.x; y01 += r0.y; y10 += r1.x; y11 += r1.y;
+      }
+      *reinterpret_cast<float2*>(y + idx) = make_float2(y00, y01);
+      *reinterpret_cast<float2*>(y + idx + W) = make_float2(y10, y11);
+    }
+}
+
+static int g_wino_dbg = 0;
+void wino_set_dbg(int d) { g_wino_dbg = d; }
+static int g_wino_mode = 0;        // 0 = by rule, 1 = off, 2..5 = whenever the shape is supported: workgroups of 64x64, 32x64, 64x32, 32x32 (channels x tiles)
+void wino_set_mode(int m) { g_wino_mode = m; }
+
+// workgroup shape for a Winograd launch: BN * 256 + NT, or 0 when the layer stays on the direct kernel
+int wino_plan(int B, int K, int N, int H, int W) {
+  if (g_wino_mode == 1) return 0;
+  if (H != W || (W != 64 && W != 32 && W != 16 && W != 8 && W != 4)) return 0;
+  if (K % 8 || N % 32 || K < 8) return 0;
+  if ((long)B * K * H * W >= (1L << 31) || (long)B * N * H * W >= (1L << 31) || (long)16 * N * K >= (1L << 28)) return 0;
+  const bool n64 = N % 64 == 0;
+  if (g_wino_mode == 2) return (n64 ? 64 : 32) * 256 + 64;
+  if (g_wino_mode == 3) return 32 * 256 + 64;
+  if (g_wino_mode == 4) return (n64 ? 64 : 32) * 256 + 32;
+  if (g_wino_mode == 5) return 32 * 256 + 32;
+  // measured per layer at B = 256 (tools/wino_bench.py): 32 channels x 64 tiles (two workgroups per CU, their phases
+  // interleave) is the best or within 2 % of the best shape wherever Winograd wins, and it wins once the launch has a
+  // workgroup per CU and at least 4 chunks; the 4x4 maps (4 tiles per image) and thin launches stay direct
+  const long tiles = (long)B * (H / 2) * (W / 2);
+  if (K < 32 || W < 8) return 0;
+  if ((tiles / 64) * (N / 32) >= 256) return 32 * 256 + 64;
+  return 0;
+}
+
+template <int GEO, int BN, int NT>
+static void wino_launch_t(const float* x, const float* U, const float* bias, const float* res, float* y, int B, int K, int N, int act,
+                          hipStream_t s) {
+  using G = WGeo<GEO, NT>;
+  const size_t lds = sizeof(float) * (16 * BN * 10 + 8 * G::RSP);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<GEO, BN, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const unsigned tg = G::TI == 1 ? (unsigned)B * G::GPI : (unsigned)((B + G::TI - 1) / G::TI);
+  hipLaunchKernelGGL((conv_wino<GEO, BN, NT>), dim3(N / BN, tg), dim3(BN * NT / 8), lds, s, x, U, bias, res, y, B, K, N, act);
+}
+
+// conv (dgrad = false: x (B,K,H,W), w (N,K,3,3)) or its input gradient (dgrad = true: x = dY (B,K=Cout,H,W), w (K,N,3,3))
+bool wino_conv(const float* x, const float* w, const float* bias, const float* res, float* y, float* U, int B, int K, int N, int H,
+               int W, int act, bool dgrad, bool weights_ready, hipStream_t s) {
+  const int plan = wino_plan(B, K, N, H, W);
+  if (!plan || !U) return false;
+  const int bn = plan >> 8, nt = plan & 255;
+  const int Cin = dgrad ? N : K, Cout = dgrad ? K : N;
+  if (!weights_ready && !(g_wino_dbg & 32)) hipLaunchKernelGGL(wino_weights, dim3((unsigned)((K * N + 255) / 256)), dim3(256), 0, s, w, U, Cin, Cout, dgrad ? 1 : 0);
+#define AFD_WINO(GEO_)                                                                            \
+  if (bn == 64 && nt == 64) wino_launch_t<GEO_, 64, 64>(x, U, bias, res, y, B, K, N, act, s);     \
+  else if (bn == 32 && nt == 64) wino_launch_t<GEO_, 32, 64>(x, U, bias, res, y, B, K, N, act, s); \
+  else if (bn == 64) wino_launch_t<GEO_, 64, 32>(x, U, bias, res, y, B, K, N, act, s);            \
+  else wino_launch_t<GEO_, 32, 32>(x, U, bias, res, y, B, K, N, act, s)
+  if (W == 64) { AFD_WINO(64); } else if (W == 32) { AFD_WINO(32); } else if (W == 16) { AFD_WINO(16); } else if (W == 8) { AFD_WINO(8); } else { AFD_WINO(4); }
+#undef AFD_WINO
+  return true;
+}
+
+}  // namespace afd

@@ -4,6 +4,8 @@ torch is used for device memory, the current HIP stream and the autograd graph -
 every byte moved on the device goes through libafd_hip.so.  All tensors are fp32, NCHW,
 contiguous, on a HIP device; anything else raises (there is no CPU / eager fallback).
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -247,6 +249,51 @@ class GroupNormFiltAct(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # F5 / F10 convolution (3x3 pad 1, 1x1)
 # ---------------------------------------------------------------------------------------------
+class _WinoWeights:
+    """Transformed 3x3 weights (G g G^T, forward and dgrad forms) kept per weight tensor while the weights do not
+    change: keyed by the tensor object, stamped with its autograd version and a global epoch that every raw
+    in-place update of the parameters (FusedAdamW.step) bumps.  Never used under stream capture: a captured step
+    must contain its own transform launches, because a replay runs after the weights moved."""
+    epoch = 0
+    store = {}
+
+    @classmethod
+    def get(cls, w, nbytes, dgrad):
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = (id(w), dgrad)
+        stamp = (w._version, cls.epoch, w.data_ptr(), nbytes)
+        if not capturing:
+            hit = cls.store.get(key)
+            if hit is not None and hit[0]() is w and hit[2] == stamp:
+                return hit[1], 1
+        u = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+        if not capturing:
+            if len(cls.store) > 512:
+                cls.store.clear()
+            try:
+                cls.store[key] = (weakref.ref(w), u, stamp)
+            except TypeError:
+                pass
+        return u, 0
+
+
+def bump_param_epoch():
+    """Call after parameters were modified through raw device pointers (the fused optimizer)."""
+    _WinoWeights.epoch += 1
+
+
+def _conv_fwd(x, w, bias, res, y, B, Cin, Cout, H, W, ks, act):
+    """3x3 layers the Winograd kernel covers go there (the library says which: a non-zero workspace size);
+    everything else takes the direct implicit-GEMM kernels."""
+    L = lib()
+    nb = L.afd_conv3x3_wino_workspace_bytes(B, Cin, Cout, H, W, 0) if ks == 3 else 0
+    if nb:
+        u, ready = _WinoWeights.get(w, nb, 0)
+        L.afd_conv3x3_wino_fwd(_p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Cout, H, W, act, _p(u), ready, _stream())
+    else:
+        L.afd_conv_fwd(_p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Cout, H, W, ks, act, _stream())
+
+
 class Conv(torch.autograd.Function):
     """y = conv(x, w) + bias + res.  (The GELU epilogue is only used by `conv_infer`.)"""
 
@@ -259,7 +306,7 @@ class Conv(torch.autograd.Function):
         B, Cin, H, W = x.shape
         Cout, ks = w.shape[0], w.shape[-1]
         y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
-        lib().afd_conv_fwd(_p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Cout, H, W, ks, 0, _stream())
+        _conv_fwd(x, w, bias, res, y, B, Cin, Cout, H, W, ks, 0)
         ctx.save_for_backward(x, w)
         ctx.has_bias, ctx.has_res = bias is not None, res is not None
         ctx.w_param, ctx.b_param = w_param, b_param
@@ -275,7 +322,12 @@ class Conv(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            L.afd_conv_dgrad(_p(dy), _p(w), _p(dx), B, Cin, Cout, H, W, ks, _stream())
+            nb = L.afd_conv3x3_wino_workspace_bytes(B, Cin, Cout, H, W, 1) if ks == 3 else 0
+            if nb:
+                u, ready = _WinoWeights.get(w, nb, 1)
+                L.afd_conv3x3_wino_dgrad(_p(dy), _p(w), _p(dx), B, Cin, Cout, H, W, _p(u), ready, _stream())
+            else:
+                L.afd_conv_dgrad(_p(dy), _p(w), _p(dx), B, Cin, Cout, H, W, ks, _stream())
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             nbytes = L.afd_conv_wgrad_workspace_bytes(B, Cin, Cout, H, W, ks)
             ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
@@ -306,7 +358,7 @@ def conv_infer(x, w, bias=None, res=None, act=0):
     B, Cin, H, W = x.shape
     Cout, ks = w.shape[0], w.shape[-1]
     y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
-    lib().afd_conv_fwd(_p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Cout, H, W, ks, act, _stream())
+    _conv_fwd(x, w, bias, res, y, B, Cin, Cout, H, W, ks, act)
     return y
 
 

@@ -97,6 +97,7 @@ class FusedAdamW:
         L.afd_adamw_step(self.fp.flat.data_ptr(), self.fp.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                          self.fp.numel, self.state.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps,
                          self.weight_decay, grad_scale, s)
+        ops.bump_param_epoch()                          # the parameters moved under raw pointers: cached transforms are stale
 
 
 class GradAllReduce:
@@ -192,6 +193,7 @@ class TrainStep:
         if eps is not None:
             st["eps"].copy_(eps)
         self._graph.replay()
+        ops.bump_param_epoch()                          # the replayed AdamW moved the parameters
         if not whole:
             self._update()
         return st["loss"]

@@ -122,6 +122,22 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias /* o
                    int B, int Cin, int Cout, int H, int W, int ksize, int accumulate,
                    void* workspace, afd_stream_t stream);
 
+/* Winograd F(2x2,3x3) form of the 3x3 forward / dgrad (same results up to fp32 re-association: every product
+ * and sum is fp32; 16 multiplies per 2x2 output tile and channel pair instead of 36).  Covers the square
+ * 64x64 ... 4x4 maps with Cin % 8 == 0 and Cout % 32 == 0 (dgrad: roles swapped).
+ * afd_conv3x3_wino_workspace_bytes returns 0 when the layer is not covered (or too small to gain): the caller
+ * then uses afd_conv_fwd / afd_conv_dgrad.  The workspace holds the transformed weights (16*Cin*Cout floats; the
+ * forward and the dgrad forms differ); weights_ready != 0 says it still holds them from an earlier call with the
+ * same w and the same pass, so the transform launch is skipped (sampling: w is constant over the 999 steps).
+ * afd_debug_conv_path: 64 / 65 = Winograd chosen by the measured rule (default) / never; 66..69 = whenever covered,
+ * with workgroups of 64x64 / 32x64 / 64x32 / 32x32 (output channels x tiles). */
+size_t afd_conv3x3_wino_workspace_bytes(int B, int Cin, int Cout, int H, int W, int dgrad);
+int afd_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
+                         int B, int Cin, int Cout, int H, int W, int act, void* workspace, int weights_ready,
+                         afd_stream_t stream);
+int afd_conv3x3_wino_dgrad(const float* dy, const float* w, float* dx,
+                           int B, int Cin, int Cout, int H, int W, void* workspace, int weights_ready, afd_stream_t stream);
+
 /* ---- F10: LayerNorm over channels of an NCHW tensor (= nn.LayerNorm([C]) on (B,L,C) tokens) ------
  * ddpm_utils.py:60,62,70.  stats_out (B,HW,2) = {mean, rstd}. */
 int afd_layernorm_c_fwd(const float* x, float* y, float* stats_out, int B, int C, int HW, float eps,

@@ -198,20 +198,26 @@ CONV_CASES = [
     (3, 64, 192, 16, 16, 1, True, False),     # in_proj at C=64: six 32-channel blocks per pixel tile
     (5, 32, 32, 4, 4, 1, True, True),         # 16-pixel images: a 32-pixel tile spans two of them, ragged last tile
     (2, 24, 40, 8, 8, 1, True, False),        # K, N not multiples of 32
+    (2, 64, 64, 32, 32, 3, False, False),     # Winograd: 4 tile groups per image
+    (5, 128, 64, 8, 8, 3, False, False),      # Winograd: four images per tile group, ragged last group
+    (2, 64, 32, 16, 16, 3, True, True),       # Winograd epilogue: bias + residual (+ GELU in the no-grad form)
+    (3, 8, 96, 16, 16, 3, False, False),      # Winograd: one chunk, three 32-channel blocks
 ]
 
 
-@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw"])
+@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "nowino"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[5]}" for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(A, case, path):
     afdm, ops, dev = A
-    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10}[path])
+    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10,
+                                        "wino64x64": 66, "wino32x64": 67, "wino64x32": 68, "wino32x32": 69, "nowino": 65}[path])
     try:
         _conv_case(ops, dev, case)
     finally:
         afdm.lib().afd_debug_conv_path(0)
         afdm.lib().afd_debug_conv_path(34)
         afdm.lib().afd_debug_conv_path(8)
+        afdm.lib().afd_debug_conv_path(64)
 
 
 def _conv_case(ops, dev, case):
