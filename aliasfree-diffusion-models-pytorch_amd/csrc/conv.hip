@@ -735,6 +735,9 @@ bool wino_conv(const float* x, const float* w, const float* bias, const float* r
                int W, int act, bool dgrad, bool weights_ready, hipStream_t s);
 void wino_set_mode(int m);
 void wino_set_dbg(int d);
+int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, int* cps, int* nchunks);
+int wgrad_wino(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
+void wgrad_wino_set_mode(int m);
 
 static inline bool use_mfma(int K, int N, int H, int W, int PT) { return N >= 8 && tile_ok(H, W, PT); }   // K < 8 (inc.conv1) rides the ragged-chunk path
 
@@ -843,9 +846,10 @@ extern "C" {
 int afd_debug_conv_path(int mode) {
   if (mode >= 8 && mode <= 10) { pw_set_mode(mode - 8); return AFD_OK; }     // 1x1 streaming kernel: 8 = by rule (default), 9 = off, 10 = forced
   if (mode >= 1000 && mode < 1064) { wino_set_dbg(mode - 1000); return AFD_OK; }   // ablation switches (tools/wino_abl.py)
+  if (mode >= 96 && mode <= 98) { wgrad_wino_set_mode(mode - 96); return AFD_OK; }   // Winograd wgrad: 96 = by rule (default), 97 = off, 98 = whenever covered
   if (mode >= 64 && mode <= 69) { wino_set_mode(mode - 64); return AFD_OK; }   // Winograd 3x3: 64 = by rule (default), 65 = off, 66..69 = forced, workgroups of 64x64 / 32x64 / 64x32 / 32x32 (channels x tiles)
   if (mode >= 32 && mode <= 34) { g_wgrad_nw = mode == 32 ? 4 : (mode == 33 ? 8 : 0); return AFD_OK; }   // wgrad waves: 4 / 8 / auto
-  AFD_REQUIRE(mode >= 0 && mode <= 2, "afd_debug_conv_path: mode must be 0 (auto), 1 (big tile), 2 (split-K tile), 8..10 (1x1 streaming auto/off/forced), 32..34 (wgrad waves 4/8/auto) or 64..67 (Winograd auto/off/forced 64/forced 32)");
+  AFD_REQUIRE(mode >= 0 && mode <= 2, "afd_debug_conv_path: mode must be 0 (auto), 1 (big tile), 2 (split-K tile), 8..10 (1x1 streaming auto/off/forced), 32..34 (wgrad waves 4/8/auto), 64..69 (Winograd fwd/dgrad auto/off/forced shapes) or 96..98 (Winograd wgrad auto/off/forced)");
   g_conv_path = mode;
   return AFD_OK;
 }
@@ -913,7 +917,12 @@ size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, in
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
   if (!tile_ok(H, W, 64)) return sizeof(float) * (size_t)B * Cout;
   // [slabs][Cout*Cin*T] weight slabs, then [slabs][Cout] bias slabs; the direct path wants (B, Cout) plane sums
-  const size_t slabs = wgrad_plan(B, Cin, Cout, H, W, ksize).slabs;
+  size_t slabs = wgrad_plan(B, Cin, Cout, H, W, ksize).slabs;
+  if (ksize == 3) {                                                      // the Winograd form may split finer
+    int bn, bk, cps, nch;
+    const size_t ws = (size_t)wgrad_wino_plan(B, Cin, Cout, H, W, &bn, &bk, &cps, &nch);
+    if (ws > slabs) slabs = ws;
+  }
   const size_t need = slabs * ((size_t)Cout * Cin * ksize * ksize + Cout);
   const size_t direct = (size_t)B * Cout;
   return sizeof(float) * (need > direct ? need : direct);
@@ -926,6 +935,15 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
   hipStream_t s = as_stream(st);
   const int T = ksize * ksize;
   const TileGeom g = make_geom(H, W, 64, ksize == 3 ? 1 : 0);
+  if (ksize == 3 && !dbias && workspace) {                               // Winograd F(3x3, 2x2) form: 16 multiplies per tile instead of 36
+    float* part = static_cast<float*>(workspace);
+    const int slabs = wgrad_wino(x, dy, part, B, Cin, Cout, H, W, s);
+    if (slabs) {
+      const long n = (long)Cout * Cin * 9;
+      hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, part, dw, n, slabs, nullptr, nullptr, 0, accumulate, 9);
+      return check_launch("afd_conv_wgrad");
+    }
+  }
   if (tile_ok(H, W, 64) && g.XS <= 256 && (long)B * H * W * (Cin > Cout ? Cin : Cout) < (1L << 31)) {
     AFD_REQUIRE(workspace, "afd_conv_wgrad: workspace is NULL");
     const WgradPlan p = wgrad_plan(B, Cin, Cout, H, W, ksize);

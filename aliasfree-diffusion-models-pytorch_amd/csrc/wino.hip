@@ -303,4 +303,247 @@ bool wino_conv(const float* x, const float* w, const float* bias, const float* r
   return true;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// wgrad by the adjoint of the same factorisation:  dU[xi][n][k] = sum_tiles (A dY A^T)[xi][n][tile] * (B^T d B)[xi][k][tile],
+// dg = G^T dU G.  16 multiplies per (n, k, tile) instead of 36 (9 taps x 4 pixels).
+//   A workgroup owns BN output channels x BK input channels and a range of 16-tile chunks (split over the
+//   tiles: partial slabs + the deterministic wgrad_reduce of conv.hip, same slab layout [tap][cout][cin]).
+//   Per chunk the dY rows and the haloed X rows are staged global -> registers -> LDS; each wave (32 n x 16 k) then
+//   runs 4 reduction steps of 4 tiles: lane (li, lq) transforms ITS operands in registers -- A dY A^T for rows
+//   n = li, 16 + li and B^T d B for column k = li, both at tile 4s + lq (12 + 12 + 32 adds; the minus signs of
+//   A dY A^T are applied once, in the epilogue) -- and issues 32 v_mfma_f32_16x16x4_f32.  No operand is read from
+//   LDS inside the multiply loop.  The epilogue folds G^T dU G in registers (the 16 xi of an (n, k) pair sit in one
+//   lane) and writes 9 taps.
+// ------------------------------------------------------------------------------------------
+template <int S> struct WgGeo {
+  using G = WGeo<S, 16>;
+  static constexpr int W = S, HW = S * S, Wp = G::Wp, PXR = G::PXR, TI = G::TI, RTX = PXR + 2, IMG = G::IMG, RS = G::RS;
+  static constexpr int RSX = RS + ((4 - RS % 8) + 8) % 8;          // = 4 * odd: 16 channel rows land on 16 distinct bank quads
+  static constexpr int DS = 68;                                     // dY: 64 floats per channel (16 tiles x 2 x 2), stride 4 * 17
+  static constexpr int poff(int t) { return (t / (G::TROWS * G::TPR)) * IMG + 2 * ((t / G::TPR) % G::TROWS) * Wp + 2 * (t % G::TPR); }
+  static constexpr int doff(int t) { return (t / (G::TROWS * G::TPR)) * PXR * W + 2 * ((t / G::TPR) % G::TROWS) * W + 2 * (t % G::TPR); }
+};
+
+template <int S, int BN, int BK>
+__global__ __launch_bounds__((BN / 32) * (BK / 16) * 64, (BN / 32) * (BK / 16) == 8 ? 1 : 2)
+void wgrad_wino(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                int B, int Cin, int Cout, int chunks_per_split, int nchunks) {
+  using Q = WgGeo<S>;
+  using G = WGeo<S, 16>;
+  constexpr int W = S, H = S, HW = S * S, Wp = Q::Wp, PXR = Q::PXR, TI = Q::TI, RTX = Q::RTX, IMG = Q::IMG, RSX = Q::RSX, DS = Q::DS;
+  constexpr int NWN = BN / 32, NWK = BK / 16, NTH = NWN * NWK * 64, W4 = W / 4;
+  constexpr int XUNITS = BK * TI * RTX * W4, NX = (XUNITS + NTH - 1) / NTH;        // float4 pieces per chunk / per thread
+  constexpr int DUNITS = BN * TI * PXR * W4, ND = (DUNITS + NTH - 1) / NTH;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;                                  // [BK][RSX]  haloed input rows (halo columns stay zero)
+  float* Gs = smem + BK * RSX;                       // [BN][DS]   dY rows
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n0 = blockIdx.x * BN, k0 = blockIdx.y * BK, split = blockIdx.z;
+  const int wn = wv % NWN, wk = wv / NWN;
+  const int li = lane & 15, lq = lane >> 4;
+
+  for (int i = tid; i < BK * RSX; i += NTH) Xs[i] = 0.f;
+
+  // chunk -> (first image, first pixel row): running state of the next chunk to fetch
+  const int cbeg = split * chunks_per_split, cend = min(nchunks, cbeg + chunks_per_split);
+  int f_b = (TI == 1) ? cbeg / G::GPI : cbeg * TI;
+  int f_g = (TI == 1) ? cbeg % G::GPI : 0;
+
+  f32x4 xreg[NX], greg[ND];
+  unsigned xok, gok;
+  auto fetch = [&]() {
+    const int row0 = f_g * PXR;
+    xok = 0; gok = 0;
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+      const int u = tid + NTH * e;
+      const int x4 = u % W4, ch = (u / W4) % BK, rl = u / (W4 * BK);
+      const int ti = rl / RTX, rr = rl % RTX;
+      const int yy = row0 - 1 + rr, b = f_b + ti;
+      const bool ok = (XUNITS % NTH == 0 || u < XUNITS) && yy >= 0 && yy < H && b < B;
+      const unsigned src = ok ? (unsigned)((b * Cin + k0 + ch) * HW + yy * W + 4 * x4) : 0u;
+      xreg[e] = *reinterpret_cast<const f32x4*>(x + src);
+      xok |= (ok ? 1u : 0u) << e;
+    }
+#pragma unroll
+    for (int e = 0; e < ND; ++e) {
+      const int u = tid + NTH * e;
+      const int x4 = u % W4, n = (u / W4) % BN, rl = u / (W4 * BN);
+      const int ti = rl / PXR, rr = rl % PXR;
+      const int b = f_b + ti;
+      const bool ok = (DUNITS % NTH == 0 || u < DUNITS) && b < B;
+      const unsigned src = ok ? (unsigned)((b * Cout + n0 + n) * HW + (row0 + rr) * W + 4 * x4) : 0u;
+      greg[e] = *reinterpret_cast<const f32x4*>(dy + src);
+      gok |= (ok ? 1u : 0u) << e;
+    }
+    if (TI == 1) { if (++f_g == G::GPI) { f_g = 0; ++f_b; } } else { f_b += TI; }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int e = 0; e < NX; ++e) {
+      const int u = tid + NTH * e;
+      if (XUNITS % NTH == 0 || u < XUNITS) {
+        const int x4 = u % W4, ch = (u / W4) % BK, rl = u / (W4 * BK);
+        float* d = Xs + ch * RSX + (rl / RTX) * IMG + (rl % RTX) * Wp + 1 + 4 * x4;
+        const bool ok = (xok >> e) & 1u;
+        d[0] = ok ? xreg[e][0] : 0.f; d[1] = ok ? xreg[e][1] : 0.f; d[2] = ok ? xreg[e][2] : 0.f; d[3] = ok ? xreg[e][3] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < ND; ++e) {
+      const int u = tid + NTH * e;
+      if (DUNITS % NTH == 0 || u < DUNITS) {
+        const int x4 = u % W4, n = (u / W4) % BN, rl = u / (W4 * BN);
+        const bool ok = (gok >> e) & 1u;
+        f32x4 v = greg[e];
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(Gs + n * DS + (rl / PXR) * PXR * W + (rl % PXR) * W + 4 * x4) = v;
+      }
+    }
+  };
+
+  const float* xp = Xs + (wk * 16 + li) * RSX + Q::poff(0) + (lq == 0 ? Q::poff(0) : lq == 1 ? Q::poff(1) : lq == 2 ? Q::poff(2) : Q::poff(3));
+  const float* gp = Gs + (wn * 32 + li) * DS + (lq == 0 ? Q::doff(0) : lq == 1 ? Q::doff(1) : lq == 2 ? Q::doff(2) : Q::doff(3));
+
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[xi][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (cbeg < cend) fetch();
+  for (int c = cbeg; c < cend; ++c) {
+    __syncthreads();                                  // the previous chunk's transforms are done with Xs / Gs (first pass: the zero fill)
+    commit();
+    if (c + 1 < cend) fetch();                        // in flight during the multiplies
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      // B operand: V = B^T d B of (channel wk*16 + li, tile 4s + lq)
+      float v[16];
+      {
+        const float* r = xp + Q::poff(4 * s);
+        float d[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const float2 lo = *reinterpret_cast<const float2*>(r + a * Wp);
+          const float2 hi = *reinterpret_cast<const float2*>(r + a * Wp + 2);
+          d[a][0] = lo.x; d[a][1] = lo.y; d[a][2] = hi.x; d[a][3] = hi.y;
+        }
+        float w[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          w[0][j] = d[0][j] - d[2][j];
+          w[1][j] = d[1][j] + d[2][j];
+          w[2][j] = d[2][j] - d[1][j];
+          w[3][j] = d[1][j] - d[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[4 * i + 0] = w[i][0] - w[i][2];
+          v[4 * i + 1] = w[i][1] + w[i][2];
+          v[4 * i + 2] = w[i][2] - w[i][1];
+          v[4 * i + 3] = w[i][1] - w[i][3];
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // A operand: |A dY A^T| of (channel wn*32 + 16h + li, tile 4s + lq); entries 3, 7, 11, 12, 13, 14 carry a minus
+        // sign that the epilogue applies
+        const float* q = gp + h * 16 * DS + Q::doff(4 * s);
+        const float2 r0 = *reinterpret_cast<const float2*>(q), r1 = *reinterpret_cast<const float2*>(q + W);
+        const float a = r0.x, b = r0.y, cc = r1.x, d = r1.y;
+        const float ac = a + cc, bd = b + d, amc = a - cc, bmd = b - d;
+        float m[16];
+        m[0] = a;    m[1] = a + b;     m[2] = a - b;     m[3] = b;
+        m[4] = ac;   m[5] = ac + bd;   m[6] = ac - bd;   m[7] = bd;
+        m[8] = amc;  m[9] = amc + bmd; m[10] = amc - bmd; m[11] = bmd;
+        m[12] = cc;  m[13] = cc + d;   m[14] = cc - d;   m[15] = d;
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) acc[xi][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(m[xi], v[xi], acc[xi][h], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: dg = G^T dU G with G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]; slab layout [tap][cout][cin]
+  float* out = part + (long)split * Cout * Cin * 9;
+  const int kk = k0 + wk * 16 + li;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * 32 + 16 * h + 4 * lq + r;
+      float t[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sg3 = (j == 3) ? 1.f : -1.f;               // row 3 of |A dY A^T|: -, -, -, +
+        const float u0 = (j == 3) ? -acc[j][h][r] : acc[j][h][r];
+        const float u1 = (j == 3) ? -acc[4 + j][h][r] : acc[4 + j][h][r];
+        const float u2 = (j == 3) ? -acc[8 + j][h][r] : acc[8 + j][h][r];
+        const float u3 = sg3 * acc[12 + j][h][r];
+        const float hs = 0.5f * (u1 + u2), hd = 0.5f * (u1 - u2);
+        t[0][j] = u0 + hs; t[1][j] = hd; t[2][j] = hs + u3;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float hs = 0.5f * (t[a][1] + t[a][2]), hd = 0.5f * (t[a][1] - t[a][2]);
+        out[((long)(3 * a + 0) * Cout + n) * Cin + kk] = t[a][0] + hs;
+        out[((long)(3 * a + 1) * Cout + n) * Cin + kk] = hd;
+        out[((long)(3 * a + 2) * Cout + n) * Cin + kk] = hs + t[a][3];
+      }
+    }
+}
+
+static int g_wgwino_mode = 0;      // 0 = by rule, 1 = off, 2 = whenever covered
+void wgrad_wino_set_mode(int m) { g_wgwino_mode = m; }
+
+// Winograd wgrad plan: returns the number of slabs (0 = not covered / not chosen); fills the block shape and split
+int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, int* cps, int* nchunks) {
+  if (g_wgwino_mode == 1) return 0;
+  if (H != W || (W != 32 && W != 16 && W != 8 && W != 4)) return 0;
+  if (Cin % 32 || Cout % 32) return 0;
+  if ((long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return 0;
+  const int tpi = (W / 2) * (W / 2);
+  const int nch = tpi >= 16 ? B * (tpi / 16) : (B + 16 / tpi - 1) / (16 / tpi);
+  const int BN = Cout % 64 == 0 ? 64 : 32, BK = Cin % 64 == 0 ? 64 : 32;
+  const int waves = (BN / 32) * (BK / 16);
+  const long blocks = (long)(Cout / BN) * (Cin / BK);
+  long s = (256L * (waves == 8 ? 1 : (waves == 4 ? 2 : 4))) / blocks;
+  if (s < 1) s = 1;
+  if (s > nch) s = nch;
+  const int c = (int)((nch + s - 1) / s);
+  *bn = BN; *bk = BK; *cps = c; *nchunks = nch;
+  return (nch + c - 1) / c;
+}
+
+template <int S, int BN, int BK>
+static void wgrad_wino_launch_t(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int cps, int nch, int splits,
+                                hipStream_t s) {
+  using Q = WgGeo<S>;
+  const size_t lds = sizeof(float) * ((size_t)BK * Q::RSX + (size_t)BN * Q::DS);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino<S, BN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_wino<S, BN, BK>), dim3(Cout / BN, Cin / BK, splits), dim3((BN / 32) * (BK / 16) * 64), lds, s,
+                     x, dy, part, B, Cin, Cout, cps, nch);
+}
+
+// writes `slabs` partial [9][Cout][Cin] slabs into part; the caller reduces them (wgrad_reduce)
+int wgrad_wino(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s) {
+  int bn, bk, cps, nch;
+  const int splits = wgrad_wino_plan(B, Cin, Cout, H, W, &bn, &bk, &cps, &nch);
+  if (!splits) return 0;
+#define AFD_WGW(S_)                                                                                              \
+  if (bn == 64 && bk == 64) wgrad_wino_launch_t<S_, 64, 64>(x, dy, part, B, Cin, Cout, cps, nch, splits, s);     \
+  else if (bn == 32 && bk == 64) wgrad_wino_launch_t<S_, 32, 64>(x, dy, part, B, Cin, Cout, cps, nch, splits, s); \
+  else if (bn == 64) wgrad_wino_launch_t<S_, 64, 32>(x, dy, part, B, Cin, Cout, cps, nch, splits, s);            \
+  else wgrad_wino_launch_t<S_, 32, 32>(x, dy, part, B, Cin, Cout, cps, nch, splits, s)
+  if (W == 32) { AFD_WGW(32); } else if (W == 16) { AFD_WGW(16); } else if (W == 8) { AFD_WGW(8); } else { AFD_WGW(4); }
+#undef AFD_WGW
+  return splits;
+}
+
 }  // namespace afd

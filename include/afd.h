@@ -111,7 +111,8 @@ int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, in
 /* test hook: 0 = choose the tile by workgroup count (default), 1 = always the 64x128 tile,
  * 2 = always the 32x64 in-workgroup split-K tile (when the shape allows it);
  * 8 / 9 / 10 = 1x1 streaming kernel chosen by the measured rule (default) / never / whenever the shape is covered;
- * 32 / 33 / 34 = wgrad workgroups of 4 waves / 8 waves / chosen per layer (default) */
+ * 32 / 33 / 34 = wgrad workgroups of 4 waves / 8 waves / chosen per layer (default);
+ * 96 / 97 / 98 = Winograd form of the 3x3 wgrad chosen by rule (default) / never / whenever the shape is covered */
 int afd_debug_conv_path(int mode);
 int afd_conv_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
                  int B, int Cin, int Cout, int H, int W, int ksize, int act, afd_stream_t stream);

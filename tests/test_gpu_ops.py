@@ -205,12 +205,12 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "nowino"])
+@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "nowino", "wgwino", "nowgwino"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[5]}" for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(A, case, path):
     afdm, ops, dev = A
     afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10,
-                                        "wino64x64": 66, "wino32x64": 67, "wino64x32": 68, "wino32x32": 69, "nowino": 65}[path])
+                                        "wino64x64": 66, "wino32x64": 67, "wino64x32": 68, "wino32x32": 69, "nowino": 65, "wgwino": 98, "nowgwino": 97}[path])
     try:
         _conv_case(ops, dev, case)
     finally:
@@ -218,6 +218,7 @@ def test_conv_fwd_dgrad_wgrad(A, case, path):
         afdm.lib().afd_debug_conv_path(34)
         afdm.lib().afd_debug_conv_path(8)
         afdm.lib().afd_debug_conv_path(64)
+        afdm.lib().afd_debug_conv_path(96)
 
 
 def _conv_case(ops, dev, case):
