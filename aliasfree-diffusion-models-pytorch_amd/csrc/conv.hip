@@ -735,6 +735,8 @@ bool wino_conv(const float* x, const float* w, const float* bias, const float* r
                int W, int act, bool dgrad, bool weights_ready, hipStream_t s);
 void wino_set_mode(int m);
 void wino_set_dbg(int d);
+void wino_weights_launch(const float* w, float* Uf, float* Ud, int Cin, int Cout, hipStream_t s);
+void wino_set_grid(int g);
 int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, int* cps, int* nchunks);
 int wgrad_wino(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
 void wgrad_wino_set_mode(int m);
@@ -845,6 +847,7 @@ extern "C" {
 
 int afd_debug_conv_path(int mode) {
   if (mode >= 8 && mode <= 10) { pw_set_mode(mode - 8); return AFD_OK; }     // 1x1 streaming kernel: 8 = by rule (default), 9 = off, 10 = forced
+  if (mode >= 100000 && mode < 200000) { wino_set_grid(mode - 100000); return AFD_OK; }   // Winograd persistent grid size (0 = default)
   if (mode >= 1000 && mode < 1064) { wino_set_dbg(mode - 1000); return AFD_OK; }   // ablation switches (tools/wino_abl.py)
   if (mode >= 96 && mode <= 98) { wgrad_wino_set_mode(mode - 96); return AFD_OK; }   // Winograd wgrad: 96 = by rule (default), 97 = off, 98 = whenever covered
   if (mode >= 64 && mode <= 69) { wino_set_mode(mode - 64); return AFD_OK; }   // Winograd 3x3: 64 = by rule (default), 65 = off, 66..69 = forced, workgroups of 64x64 / 32x64 / 64x32 / 32x32 (channels x tiles)
@@ -894,6 +897,12 @@ size_t afd_conv3x3_wino_workspace_bytes(int B, int Cin, int Cout, int H, int W, 
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
   const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
   return wino_plan(B, K, N, H, W) ? sizeof(float) * 16 * (size_t)Cin * Cout : 0;
+}
+
+int afd_conv3x3_wino_weights(const float* w, float* u_fwd, float* u_dgrad, int Cin, int Cout, afd_stream_t st) {
+  AFD_REQUIRE(w && (u_fwd || u_dgrad) && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, "afd_conv3x3_wino_weights: bad argument");
+  wino_weights_launch(w, u_fwd, u_dgrad, Cin, Cout, as_stream(st));
+  return check_launch("afd_conv3x3_wino_weights");
 }
 
 int afd_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,

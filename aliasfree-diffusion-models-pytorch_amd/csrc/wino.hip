@@ -19,6 +19,7 @@
 namespace afd {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 // geometry of an NT-tile workgroup on a square S x S map: either TROWS rows of tiles of ONE image (NT <= tiles per
 // image) or TI whole images.  The haloed input rows of the group live in LDS as [channel][TI][RROWS][Wp].
@@ -32,26 +33,35 @@ template <int S, int NT> struct WGeo {
   static_assert(NT % TPR == 0 && (NT <= TPI ? TPI % NT == 0 : NT % TPI == 0), "tile group must be whole tile rows or whole images");
 };
 
+// hand-issued LDS fragment reads: two ds_read_b64 at base + immediate offsets, and the counted wait that makes their
+// results usable (the registers go through the wait statement, so no consumer can be scheduled above it)
+template <int OFF0, int OFF1>
+__device__ __forceinline__ void lds_issue_pair(f32x2& a, f32x2& b, unsigned base) {
+  asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4" : "=&v"(a), "=&v"(b) : "v"(base), "n"(OFF0), "n"(OFF1));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(f32x2& a, f32x2& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
 __device__ __forceinline__ int kperm8(int k) { return 2 * (k & 3) + (k >> 2); }   // LDS slot of channel k of a chunk: lane quarter q reads k = q, q + 4 as one b64
 
-// U[(k>>3)][xi][n][kperm8(k&7)] = (G g G^T)[xi] with g = w[n][k] (forward) or the flipped w[k][n] (dgrad)
-__global__ __launch_bounds__(256) void wino_weights(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout, int dgrad) {
-  const int Nn = dgrad ? Cin : Cout, Kk = dgrad ? Cout : Cin;
+// Transformed weights of one 3x3 layer, either or both passes in one launch:
+//   Uf[(ci>>3)][xi][co][kperm8(ci&7)] = (G g G^T)[xi],  g = w[co][ci]                      (forward: reduction over ci)
+//   Ud[(co>>3)][xi'][ci][kperm8(co&7)] = (G g' G^T)[xi'], g' = w[co][ci] rotated by 180 deg  (dgrad: reduction over co)
+// G J = P G with P swapping rows 0 and 3 (J the 3x3 flip), so the dgrad form is the forward form with the xi indices
+// permuted: no second transform.
+__global__ __launch_bounds__(256) void wino_weights(const float* __restrict__ w, float* __restrict__ Uf, float* __restrict__ Ud,
+                                                    int Cin, int Cout) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Nn * Kk) return;
-  const int k = idx % Kk, n = idx / Kk;
+  if (idx >= Cin * Cout) return;
+  const int ci = idx % Cin, co = idx / Cin;
+  const float* p = w + (long)idx * 9;
   float g[9];
-  if (!dgrad) {
-    const float* p = w + ((long)n * Cin + k) * 9;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) g[t] = p[t];
-  } else {
-    const float* p = w + ((long)k * Cin + n) * 9;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) g[t] = p[8 - t];
-  }
+  for (int t = 0; t < 9; ++t) g[t] = p[t];
   // t = G g  (4x3), u = t G^T (4x4);  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
-  float t[4][3];
+  float t[4][3], u[16];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float g0 = g[c], g1 = g[3 + c], g2 = g[6 + c];
@@ -60,60 +70,75 @@ __global__ __launch_bounds__(256) void wino_weights(const float* __restrict__ w,
     t[2][c] = 0.5f * (g0 - g1 + g2);
     t[3][c] = g2;
   }
-  float* o = U + ((long)(k >> 3) * 16 * Nn + n) * 8 + kperm8(k & 7);
-  const long xs = (long)Nn * 8;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float a = t[i][0], b = t[i][1], c = t[i][2];
-    o[(4 * i + 0) * xs] = a;
-    o[(4 * i + 1) * xs] = 0.5f * (a + b + c);
-    o[(4 * i + 2) * xs] = 0.5f * (a - b + c);
-    o[(4 * i + 3) * xs] = c;
+    u[4 * i + 0] = a;
+    u[4 * i + 1] = 0.5f * (a + b + c);
+    u[4 * i + 2] = 0.5f * (a - b + c);
+    u[4 * i + 3] = c;
+  }
+  if (Uf) {
+    float* o = Uf + ((long)(ci >> 3) * 16 * Cout + co) * 8 + kperm8(ci & 7);
+    const long xs = (long)Cout * 8;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) o[xi * xs] = u[xi];
+  }
+  if (Ud) {
+    float* o = Ud + ((long)(co >> 3) * 16 * Cin + ci) * 8 + kperm8(co & 7);
+    const long xs = (long)Cin * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pi = i == 0 ? 3 : (i == 3 ? 0 : i), pj = j == 0 ? 3 : (j == 3 ? 0 : j);
+        o[(4 * i + j) * xs] = u[4 * pi + pj];
+      }
   }
 }
 
 template <int GEO, int BN, int NT>
 __global__ __launch_bounds__(BN * NT / 8, BN * NT == 4096 ? 1 : 2) void conv_wino(const float* __restrict__ x, const float* __restrict__ U,
                                                     const float* __restrict__ bias, const float* __restrict__ res,
-                                                    float* __restrict__ y, int B, int K, int N, int act) {
+                                                    float* __restrict__ y, int B, int K, int N, int act, int items) {
   using G = WGeo<GEO, NT>;
   constexpr int KC = 8, SU = 10, NTH = BN * NT / 8;                        // one wave per 32 channels x 16 tiles
   constexpr int W = G::W, H = G::W, HW = W * W, Wp = G::Wp, IMG = G::IMG, RS = G::RS, RSP = G::RSP;
   constexpr int NPOS = (RS + NTH - 1) / NTH;         // raw positions per thread
   constexpr int NUV = 16 * BN * 2 / NTH;             // float4 pieces of the U chunk per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Us = smem;                                  // [16][BN][SU]
-  float* Rs = Us + 16 * BN * SU;                     // [KC][RSP]   haloed input rows
+  constexpr int BUF = 16 * BN * SU + KC * RSP;       // floats per stage: U image [row block][16 xi][16 rows][SU], then the
+  float* Us = smem;                                  // haloed input rows [KC][RSP]; TWO stages: chunk c+1 is written while
+  float* Rs = Us + 16 * BN * SU;                     // chunk c is multiplied, one barrier per chunk
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int n0 = blockIdx.x * BN;
-  const int tg = blockIdx.y;
-  const int b0 = (G::TI == 1) ? tg / G::GPI : tg * G::TI;
-  const int row0 = (G::TI == 1) ? (tg % G::GPI) * G::PXR : 0;
+  const int NB = N / BN;                             // work item w = (tile group, channel block): w % NB is the channel block
 
-  // ---- staging plans (chunk-invariant)
-  unsigned rsrc[NPOS]; bool rval[NPOS]; int rpos[NPOS];
-#pragma unroll
-  for (int e = 0; e < NPOS; ++e) {
-    const int pos = tid + NTH * e;
-    rpos[e] = pos;
-    bool ok = false; unsigned src = 0;
-    if (pos < RS) {
-      const int ti = pos / IMG, rem = pos % IMG;
-      const int yy = row0 + rem / Wp - 1, xx = rem % Wp - 1, b = b0 + ti;
-      ok = b < B && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      if (ok) src = (unsigned)(b * K) * (unsigned)HW + (unsigned)(yy * W + xx);
-    }
-    rval[e] = ok; rsrc[e] = src;
-  }
-  // U pieces: piece e of a thread is the same (row, half) XSTEP xi-planes further on, so one source offset and one
-  // LDS offset serve all of them (the per-piece part is a scalar / an immediate)
+  // ---- staging plan of the item being FETCHED (it runs ahead of the item being multiplied across item seams)
+  unsigned rsrc[NPOS]; unsigned rvalid = 0; unsigned usrc0 = 0;
   constexpr int XSTEP = NTH / (2 * BN);
   static_assert(NTH % (2 * BN) == 0 && XSTEP * NUV == 16, "U chunk must split into whole xi planes per pass");
   const int u_h = tid & 1, u_n = (tid >> 1) % BN, u_xi = tid / (2 * BN);
-  const unsigned usrc0 = (unsigned)((u_xi * N + n0 + u_n) * 8 + 4 * u_h);
-  const int udst0 = (u_xi * BN + u_n) * SU + 4 * u_h;
+  const int udst0 = (((u_n >> 4) * 16 + u_xi) * 16 + (u_n & 15)) * SU + 4 * u_h;   // LDS image [row block][xi][16 rows][SU]
   const long ustep = (long)XSTEP * N * 8;
-  // transform unit(s): tile tt = tid % NT; channel kq (and kq + 4 when a thread owns two)
+  auto plan = [&](int w) {
+    const int tg = w / NB, n0 = (w % NB) * BN;
+    const int b0 = (G::TI == 1) ? tg / G::GPI : tg * G::TI;
+    const int row0 = (G::TI == 1) ? (tg % G::GPI) * G::PXR : 0;
+    rvalid = 0;
+#pragma unroll
+    for (int e = 0; e < NPOS; ++e) {
+      const int pos = tid + NTH * e;
+      bool ok = false; unsigned src = 0;
+      if (pos < RS) {
+        const int ti = pos / IMG, rem = pos % IMG;
+        const int yy = row0 + rem / Wp - 1, xx = rem % Wp - 1, b = b0 + ti;
+        ok = b < B && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        if (ok) src = (unsigned)(b * K) * (unsigned)HW + (unsigned)(yy * W + xx);
+      }
+      rsrc[e] = src; rvalid |= (ok ? 1u : 0u) << e;
+    }
+    usrc0 = (unsigned)((u_xi * N + n0 + u_n) * 8 + 4 * u_h);
+  };
   // ---- wave roles: 32 channels x 16 tiles, all 16 xi.  Lane (li, lq): A rows wn*32 + {li, 16 + li}, tile wt*16 + li,
   // channels lq and lq + 4 of the chunk (the two k-steps of v_mfma_f32_16x16x4_f32)
   const int wn = wv % (BN / 32), wt = wv / (BN / 32);
@@ -123,6 +148,7 @@ __global__ __launch_bounds__(BN * NT / 8, BN * NT == 4096 ? 1 : 2) void conv_win
 
   float rreg[NPOS][KC];
   f32x4 ureg[NUV];
+  unsigned rcommit = 0;                              // validity bits of the positions held in rreg
   auto fetch = [&](int c) {
     const float* __restrict__ xk = x + (long)c * KC * HW;
     const float* __restrict__ uk = U + (long)c * 16 * N * 8;
@@ -130,27 +156,31 @@ __global__ __launch_bounds__(BN * NT / 8, BN * NT == 4096 ? 1 : 2) void conv_win
     for (int e = 0; e < NUV; ++e) ureg[e] = *reinterpret_cast<const f32x4*>(uk + e * ustep + usrc0);
 #pragma unroll
     for (int e = 0; e < NPOS; ++e)
-      if (rpos[e] < RS) {
+      if (tid + NTH * e < RS) {
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) rreg[e][kc] = xk[rsrc[e] + (unsigned)(kc * HW)];
+        for (int kc = 0; kc < KC; ++kc) rreg[e][kc] = (xk + kc * HW)[rsrc[e]];      // scalar base per channel, one lane offset
       }
+    rcommit = rvalid;
   };
-  auto commit = [&]() {
+  auto commit = [&](int stage) {
+    float* Us = smem + stage * BUF;
+    float* Rs = Us + 16 * BN * SU;
 #pragma unroll
     for (int e = 0; e < NUV; ++e) {
-      float2* d = reinterpret_cast<float2*>(Us + udst0 + e * (XSTEP * BN * SU));
+      float2* d = reinterpret_cast<float2*>(Us + udst0 + e * (XSTEP * 16 * SU));
       d[0] = make_float2(ureg[e][0], ureg[e][1]);
       d[1] = make_float2(ureg[e][2], ureg[e][3]);
     }
 #pragma unroll
     for (int e = 0; e < NPOS; ++e)
-      if (rpos[e] < RS) {
+      if (tid + NTH * e < RS) {
+        const bool ok = (rcommit >> e) & 1u;
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) Rs[kc * RSP + rpos[e]] = rval[e] ? rreg[e][kc] : 0.f;
+        for (int kc = 0; kc < KC; ++kc) Rs[kc * RSP + tid + NTH * e] = ok ? rreg[e][kc] : 0.f;
       }
   };
   // V = B^T d B for one 4x4 patch; B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
-  auto patch = [&](int k, float (&v)[16]) {
+  auto patch = [&](const float* Rs, int k, float (&v)[16]) {
     const float* r = Rs + k * RSP + poff;
     float d[4][4];
 #pragma unroll
@@ -175,77 +205,110 @@ __global__ __launch_bounds__(BN * NT / 8, BN * NT == 4096 ? 1 : 2) void conv_win
       v[4 * i + 3] = w[i][1] - w[i][3];
     }
   };
-  const float* ap = Us + (wn * 32 + li) * SU + 2 * lq;
-  auto lds_pair = [&](const float* p) {               // one ds_read2_b64: the b64 at p and the one 16 rows further on
-    const float2 lo = *reinterpret_cast<const float2*>(p), hi = *reinterpret_cast<const float2*>(p + 16 * SU);
-    return make_float4(lo.x, lo.y, hi.x, hi.y);
-  };
-
-  f32x4 acc[16][2];
-#pragma unroll
-  for (int xi = 0; xi < 16; ++xi)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) acc[xi][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+  // byte address (LDS offset) of the lane's A fragment: rows li of the wave's two 16-row blocks, channels lq and lq + 4.
+  // The fragment reads are hand-issued ds_read_b64 with immediate offsets (xi * 640 B, second block + 10240 B): the
+  // compiler's merged ds_read2 forms need a fresh base register per xi.
+  const unsigned ap = (unsigned)(size_t)(Us + (wn * 2 * 256 + li) * SU + 2 * lq);
+  const int o_ti = tt / (G::TROWS * G::TPR), o_ty = (tt / G::TPR) % G::TROWS, o_tx = tt % G::TPR;
   const int nchunks = K / KC;
+
+  // ---- persistent loop over work items: the workgroup walks items blockIdx.x, + gridDim.x, ...; the first chunk of the
+  // next item is fetched under the last chunk of this one and the output stores drain under the next item's multiplies
+  int w = blockIdx.x;
+  if (w >= items) return;
+  plan(w);
   fetch(0);
-  for (int c = 0; c < nchunks; ++c) {
-    __syncthreads();                                  // the previous chunk's multiplies are done with Us / Rs
-    commit();
-    if (c + 1 < nchunks) fetch(c + 1);                // in flight during the transform and the multiplies
-    __syncthreads();
-    // A fragments run one xi ahead of the multiplies (the first pair is in flight under the transform)
-    float4 an = lds_pair(ap);
-    // the wave's own B operands: V = B^T d B of its 16 tiles x 8 channels, straight into registers (the waves that
-    // share these tiles repeat the 32 adds; no V image in LDS, no third barrier)
-    float v0[16], v1[16];
-    patch(lq, v0);
-    patch(lq + 4, v1);
+  for (; w < items; w += gridDim.x) {
+    f32x4 acc[16][2];
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi) {
-      const float4 a = an;                            // {a0.x, a0.y, a1.x, a1.y}: rows li and 16 + li, channels lq and lq + 4
-      if (xi < 15) an = lds_pair(ap + (xi + 1) * BN * SU);
-      __builtin_amdgcn_sched_barrier(0);              // the next pair's read stays ABOVE these multiplies
-      acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, v0[xi], acc[xi][0], 0, 0, 0);
-      acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, v0[xi], acc[xi][1], 0, 0, 0);
-      acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, v1[xi], acc[xi][0], 0, 0, 0);
-      acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, v1[xi], acc[xi][1], 0, 0, 0);
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc[xi][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // stage 0 <- chunk 0 (fetched by the previous item's tail or the prologue); chunk 1 in flight
+    __syncthreads();                                    // (the previous item's last multiplies are done with stage 0)
+    commit(0);
+    if (nchunks > 1) fetch(1);
+    else if (w + (int)gridDim.x < items) { plan(w + gridDim.x); fetch(0); }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+      const int st = c & 1;
+      const float* Rc = Rs + st * BUF;
+      const unsigned apc = ap + (unsigned)(st * BUF * 4);
+      // A fragments run one xi ahead of the multiplies (the first pair is in flight under the transform)
+      f32x2 alo[2], ahi[2];
+      lds_issue_pair<0, 256 * SU * 4>(alo[0], ahi[0], apc);
+      // the wave's own B operands: V = B^T d B of its 16 tiles x 8 channels, straight into registers (the waves that
+      // share these tiles repeat the 32 adds; no V image in LDS)
+      float v0[16], v1[16];
+      patch(Rc, lq, v0);
+      patch(Rc, lq + 4, v1);
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) {
+        constexpr int STEP = 16 * SU * 4;
+        f32x2& lo = alo[xi & 1]; f32x2& hi = ahi[xi & 1];
+        if (xi < 15) {
+          switch (xi) {                                   // (immediates must be literal per instruction)
+#define AFD_NEXT(X) case X: lds_issue_pair<(X + 1) * STEP, (X + 1) * STEP + 256 * SU * 4>(alo[(X + 1) & 1], ahi[(X + 1) & 1], apc); break;
+            AFD_NEXT(0) AFD_NEXT(1) AFD_NEXT(2) AFD_NEXT(3) AFD_NEXT(4) AFD_NEXT(5) AFD_NEXT(6) AFD_NEXT(7)
+            AFD_NEXT(8) AFD_NEXT(9) AFD_NEXT(10) AFD_NEXT(11) AFD_NEXT(12) AFD_NEXT(13) AFD_NEXT(14)
+#undef AFD_NEXT
+          }
+          lds_wait<2>(lo, hi);                            // this xi's pair landed; the next pair stays in flight
+        } else {
+          lds_wait<0>(lo, hi);
+        }
+        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(lo[0], v0[xi], acc[xi][0], 0, 0, 0);
+        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(hi[0], v0[xi], acc[xi][1], 0, 0, 0);
+        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(lo[1], v1[xi], acc[xi][0], 0, 0, 0);
+        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(hi[1], v1[xi], acc[xi][1], 0, 0, 0);
+      }
+      // chunk c+1 (in registers since one chunk ago) -> the other stage, while slower waves still multiply chunk c
+      if (c + 1 < nchunks) {
+        commit(st ^ 1);
+        if (c + 2 < nchunks) fetch(c + 2);
+        else if (w + (int)gridDim.x < items) { plan(w + gridDim.x); fetch(0); }
+        __syncthreads();                                  // stage st^1 complete; stage st free for chunk c+2
+      }
+    }
+
+    // ---- output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) and the epilogue.  Lane: tile wt*16 + li,
+    // channels n0 + wn*32 + 16*h + 4*lq + r.
+    const int tg = w / NB, n0 = (w % NB) * BN;
+    const int ob = ((G::TI == 1) ? tg / G::GPI : tg * G::TI) + o_ti;
+    const int row0 = (G::TI == 1) ? (tg % G::GPI) * G::PXR : 0;
+    if (ob < B) {
+      const int opix = (row0 + 2 * o_ty) * W + 2 * o_tx;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wn * 32 + 16 * h + 4 * lq + r;
+          float tcol[4][2];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float m0 = acc[4 * i + 0][h][r], m1 = acc[4 * i + 1][h][r], m2 = acc[4 * i + 2][h][r], m3 = acc[4 * i + 3][h][r];
+            tcol[i][0] = (m0 + m1) + m2;
+            tcol[i][1] = (m1 - m2) - m3;
+          }
+          float y00 = (tcol[0][0] + tcol[1][0]) + tcol[2][0], y01 = (tcol[0][1] + tcol[1][1]) + tcol[2][1];
+          float y10 = (tcol[1][0] - tcol[2][0]) - tcol[3][0], y11 = (tcol[1][1] - tcol[2][1]) - tcol[3][1];
+          const unsigned idx = (unsigned)((ob * N + n) * HW + opix);          // < 2^31 (host check)
+          if (bias) { const float bb = bias[n]; y00 += bb; y01 += bb; y10 += bb; y11 += bb; }
+          if (act == 1) { y00 = gelu_erf(y00); y01 = gelu_erf(y01); y10 = gelu_erf(y10); y11 = gelu_erf(y11); }
+          if (res) {
+            const float2 r0 = *reinterpret_cast<const float2*>(res + idx), r1 = *reinterpret_cast<const float2*>(res + idx + W);
+            y00 += r0.x; y01 += r0.y; y10 += r1.x; y11 += r1.y;
+          }
+          *reinterpret_cast<float2*>(y + idx) = make_float2(y00, y01);
+          *reinterpret_cast<float2*>(y + idx + W) = make_float2(y10, y11);
+        }
     }
   }
-
-  // ---- output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) and the epilogue.  Lane: tile wt*16 + li,
-  // channels n0 + wn*32 + 16*h + 4*lq + r.
-  const int ot = tt;
-  const int o_ti = ot / (G::TROWS * G::TPR), o_ty = (ot / G::TPR) % G::TROWS, o_tx = ot % G::TPR;
-  const int ob = b0 + o_ti;
-  if (ob >= B) return;
-  const int opix = (row0 + 2 * o_ty) * W + 2 * o_tx;
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * 32 + 16 * h + 4 * lq + r;
-      float tcol[4][2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float m0 = acc[4 * i + 0][h][r], m1 = acc[4 * i + 1][h][r], m2 = acc[4 * i + 2][h][r], m3 = acc[4 * i + 3][h][r];
-        tcol[i][0] = (m0 + m1) + m2;
-        tcol[i][1] = (m1 - m2) - m3;
-      }
-      float y00 = (tcol[0][0] + tcol[1][0]) + tcol[2][0], y01 = (tcol[0][1] + tcol[1][1]) + tcol[2][1];
-      float y10 = (tcol[1][0] - tcol[2][0]) - tcol[3][0], y11 = (tcol[1][1] - tcol[2][1]) - tcol[3][1];
-      const long idx = ((long)ob * N + n) * HW + opix;
-      if (bias) { const float bb = bias[n]; y00 += bb; y01 += bb; y10 += bb; y11 += bb; }
-      if (act == 1) { y00 = gelu_erf(y00); y01 = gelu_erf(y01); y10 = gelu_erf(y10); y11 = gelu_erf(y11); }
-      if (res) {
-        const float2 r0 = *reinterpret_cast<const float2*>(res + idx), r1 = *reinterpret_cast<const float2*>(res + idx + W);
-        y00 += r0.x; y01 += r0.y; y10 += r1.x; y11 += r1.y;
-      }
-      *reinterpret_cast<float2*>(y + idx) = make_float2(y00, y01);
-      *reinterpret_cast<float2*>(y + idx + W) = make_float2(y10, y11);
-    }
 }
 
+static int g_wino_grid = 0;      // test / tuning hook: persistent grid size (0 = fill the chip once)
+void wino_set_grid(int g) { g_wino_grid = g; }
 static int g_wino_dbg = 0;
 void wino_set_dbg(int d) { g_wino_dbg = d; }
 static int g_wino_mode = 0;        // 0 = by rule, 1 = off, 2..5 = whenever the shape is supported: workgroups of 64x64, 32x64, 64x32, 32x32 (channels x tiles)
@@ -262,11 +325,12 @@ int wino_plan(int B, int K, int N, int H, int W) {
   if (g_wino_mode == 3) return 32 * 256 + 64;
   if (g_wino_mode == 4) return (n64 ? 64 : 32) * 256 + 32;
   if (g_wino_mode == 5) return 32 * 256 + 32;
-  // measured per layer at B = 256 (tools/wino_bench.py): 32 channels x 64 tiles (two workgroups per CU, their phases
-  // interleave) is the best or within 2 % of the best shape wherever Winograd wins, and it wins once the launch has a
-  // workgroup per CU and at least 4 chunks; the 4x4 maps (4 tiles per image) and thin launches stay direct
+  // measured per layer at B = 256 (tools/wino_bench.py): 64 channels x 64 tiles (8 waves, one workgroup per CU, the input
+  // transform shared by two channel blocks) is best once it gives every CU a workgroup; below that 32 x 64 (two
+  // workgroups per CU); Winograd wins from 4 chunks up; the 4x4 maps (4 tiles per image) and thin launches stay direct
   const long tiles = (long)B * (H / 2) * (W / 2);
   if (K < 32 || W < 8) return 0;
+  if (n64 && (tiles / 64) * (N / 64) >= 256) return 64 * 256 + 64;
   if ((tiles / 64) * (N / 32) >= 256) return 32 * 256 + 64;
   return 0;
 }
@@ -275,14 +339,22 @@ template <int GEO, int BN, int NT>
 static void wino_launch_t(const float* x, const float* U, const float* bias, const float* res, float* y, int B, int K, int N, int act,
                           hipStream_t s) {
   using G = WGeo<GEO, NT>;
-  const size_t lds = sizeof(float) * (16 * BN * 10 + 8 * G::RSP);
+  const size_t lds = 2 * sizeof(float) * (16 * BN * 10 + 8 * G::RSP);   // two stages
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<GEO, BN, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  const unsigned tg = G::TI == 1 ? (unsigned)B * G::GPI : (unsigned)((B + G::TI - 1) / G::TI);
-  hipLaunchKernelGGL((conv_wino<GEO, BN, NT>), dim3(N / BN, tg), dim3(BN * NT / 8), lds, s, x, U, bias, res, y, B, K, N, act);
+  const int tg = G::TI == 1 ? B * G::GPI : (B + G::TI - 1) / G::TI;
+  const int items = tg * (N / BN);
+  // persistent grid: as many workgroups as fit the chip at once (8-wave groups: one per CU, smaller ones: two), each
+  // walking items g, g + grid, ...  (g_wino_grid overrides, tools/wino_bench.py)
+  // one item per workgroup by default: with two workgroups per CU the hardware's own dispatch already overlaps one
+  // group's prologue / store tail with the other's multiplies, and balances better than a fixed walk (measured);
+  // g_wino_grid > 0 makes the groups persistent (tools)
+  int grid = g_wino_grid > 0 ? g_wino_grid : items;
+  if (grid > items) grid = items;
+  hipLaunchKernelGGL((conv_wino<GEO, BN, NT>), dim3(grid), dim3(BN * NT / 8), lds, s, x, U, bias, res, y, B, K, N, act, items);
 }
 
 // conv (dgrad = false: x (B,K,H,W), w (N,K,3,3)) or its input gradient (dgrad = true: x = dY (B,K=Cout,H,W), w (K,N,3,3))
@@ -292,7 +364,8 @@ bool wino_conv(const float* x, const float* w, const float* bias, const float* r
   if (!plan || !U) return false;
   const int bn = plan >> 8, nt = plan & 255;
   const int Cin = dgrad ? N : K, Cout = dgrad ? K : N;
-  if (!weights_ready && !(g_wino_dbg & 32)) hipLaunchKernelGGL(wino_weights, dim3((unsigned)((K * N + 255) / 256)), dim3(256), 0, s, w, U, Cin, Cout, dgrad ? 1 : 0);
+  if (!weights_ready && !(g_wino_dbg & 32))
+    hipLaunchKernelGGL(wino_weights, dim3((unsigned)((K * N + 255) / 256)), dim3(256), 0, s, w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout);
 #define AFD_WINO(GEO_)                                                                            \
   if (bn == 64 && nt == 64) wino_launch_t<GEO_, 64, 64>(x, U, bias, res, y, B, K, N, act, s);     \
   else if (bn == 32 && nt == 64) wino_launch_t<GEO_, 32, 64>(x, U, bias, res, y, B, K, N, act, s); \
@@ -468,12 +541,13 @@ void wgrad_wino(const float* __restrict__ x, const float* __restrict__ dy, float
 
   // ---- epilogue: dg = G^T dU G with G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]; slab layout [tap][cout][cin]
   float* out = part + (long)split * Cout * Cin * 9;
+  const long plane = (long)Cout * Cin;
   const int kk = k0 + wk * 16 + li;
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * 32 + 16 * h + 4 * lq + r;
+      const unsigned o = (unsigned)((n0 + wn * 32 + 16 * h + 4 * lq + r) * Cin + kk);     // lane offset inside a tap plane
       float t[3][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -488,9 +562,9 @@ void wgrad_wino(const float* __restrict__ x, const float* __restrict__ dy, float
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const float hs = 0.5f * (t[a][1] + t[a][2]), hd = 0.5f * (t[a][1] - t[a][2]);
-        out[((long)(3 * a + 0) * Cout + n) * Cin + kk] = t[a][0] + hs;
-        out[((long)(3 * a + 1) * Cout + n) * Cin + kk] = hd;
-        out[((long)(3 * a + 2) * Cout + n) * Cin + kk] = hs + t[a][3];
+        (out + (3 * a + 0) * plane)[o] = t[a][0] + hs;
+        (out + (3 * a + 1) * plane)[o] = hd;
+        (out + (3 * a + 2) * plane)[o] = hs + t[a][3];
       }
     }
 }
@@ -544,6 +618,11 @@ int wgrad_wino(const float* x, const float* dy, float* part, int B, int Cin, int
   if (W == 32) { AFD_WGW(32); } else if (W == 16) { AFD_WGW(16); } else if (W == 8) { AFD_WGW(8); } else { AFD_WGW(4); }
 #undef AFD_WGW
   return splits;
+}
+
+// both (or either) transformed-weight images of a layer in one launch
+void wino_weights_launch(const float* w, float* Uf, float* Ud, int Cin, int Cout, hipStream_t s) {
+  hipLaunchKernelGGL(wino_weights, dim3((unsigned)((Cin * Cout + 255) / 256)), dim3(256), 0, s, w, Uf, Ud, Cin, Cout);
 }
 
 }  // namespace afd

@@ -282,16 +282,25 @@ def bump_param_epoch():
     _WinoWeights.epoch += 1
 
 
-def _conv_fwd(x, w, bias, res, y, B, Cin, Cout, H, W, ks, act):
+def _conv_fwd(x, w, bias, res, y, B, Cin, Cout, H, W, ks, act, want_dgrad=False):
     """3x3 layers the Winograd kernel covers go there (the library says which: a non-zero workspace size);
-    everything else takes the direct implicit-GEMM kernels."""
+    everything else takes the direct implicit-GEMM kernels.  With want_dgrad the transformed weights of the
+    backward pass are produced by the same launch as the forward ones and returned for Conv.backward."""
     L = lib()
     nb = L.afd_conv3x3_wino_workspace_bytes(B, Cin, Cout, H, W, 0) if ks == 3 else 0
+    nd = L.afd_conv3x3_wino_workspace_bytes(B, Cin, Cout, H, W, 1) if (ks == 3 and want_dgrad) else 0
+    ud = None
     if nb:
         u, ready = _WinoWeights.get(w, nb, 0)
+        if nd:
+            ud, dready = _WinoWeights.get(w, nd, 1)
+            if not (ready and dready):
+                L.afd_conv3x3_wino_weights(_p(w), _p(u), _p(ud), Cin, Cout, _stream())
+                ready = 1
         L.afd_conv3x3_wino_fwd(_p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Cout, H, W, act, _p(u), ready, _stream())
     else:
         L.afd_conv_fwd(_p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Cout, H, W, ks, act, _stream())
+    return ud
 
 
 class Conv(torch.autograd.Function):
@@ -306,7 +315,7 @@ class Conv(torch.autograd.Function):
         B, Cin, H, W = x.shape
         Cout, ks = w.shape[0], w.shape[-1]
         y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
-        _conv_fwd(x, w, bias, res, y, B, Cin, Cout, H, W, ks, 0)
+        ctx.u_dgrad = _conv_fwd(x, w, bias, res, y, B, Cin, Cout, H, W, ks, 0, want_dgrad=x.requires_grad)
         ctx.save_for_backward(x, w)
         ctx.has_bias, ctx.has_res = bias is not None, res is not None
         ctx.w_param, ctx.b_param = w_param, b_param
@@ -324,7 +333,10 @@ class Conv(torch.autograd.Function):
             dx = torch.empty_like(x)
             nb = L.afd_conv3x3_wino_workspace_bytes(B, Cin, Cout, H, W, 1) if ks == 3 else 0
             if nb:
-                u, ready = _WinoWeights.get(w, nb, 1)
+                if ctx.u_dgrad is not None:            # produced together with the forward image
+                    u, ready = ctx.u_dgrad, 1
+                else:
+                    u, ready = _WinoWeights.get(w, nb, 1)
                 L.afd_conv3x3_wino_dgrad(_p(dy), _p(w), _p(dx), B, Cin, Cout, H, W, _p(u), ready, _stream())
             else:
                 L.afd_conv_dgrad(_p(dy), _p(w), _p(dx), B, Cin, Cout, H, W, ks, _stream())

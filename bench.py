@@ -82,21 +82,16 @@ def kernel_table(dev, B):
     for (ci, co, S) in CONV3:
         key = (ci, co, S)
         if key not in seen:
-            x = torch.randn(B, ci, S, S, device=dev); w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
-            y = torch.empty(B, co, S, S, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
-            ws = torch.empty(max(L.afd_conv_wgrad_workspace_bytes(B, ci, co, S, S, 3) // 4, 1), device=dev)
-            tf = ev_time(lambda: L.afd_conv_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 3, 0, s))
-            td = ev_time(lambda: L.afd_conv_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), B, ci, co, S, S, 3, s)) if ci > 3 else 0.0
-            tw = ev_time(lambda: L.afd_conv_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, B, ci, co, S, S, 3, 0, ws.data_ptr(), s))
-            seen[key] = (tf, td, tw)
-            del x, w, y, dx, dw, ws
-        tf, td, tw = seen[key]
-        fl = 2.0 * B * S * S * ci * co * 9
-        kind = "conv3x3_fwd_mfma" if ci >= 8 else "conv3x3_fwd_direct"
-        add(kind, tf, fl)
+            seen[key] = conv_layer_times(L, s, dev, B, ci, co, S)
+        tf, td, tw, wf, wd = seen[key]
+        fl = 2.0 * B * S * S * ci * co * 9              # algorithmic (direct-form) flops of one pass
+        add("conv3x3_fwd", tf, fl)
         if ci > 3:
-            add("conv3x3_dgrad_mfma", td, fl)
-        add("conv3x3_wgrad_mfma", tw, fl)
+            add("conv3x3_dgrad", td, fl)
+        add("conv3x3_wgrad", tw, fl)
+        rows["conv3x3_fwd"]["wino"] = rows["conv3x3_fwd"].get("wino", 0) + wf
+        if ci > 3:
+            rows["conv3x3_dgrad"]["wino"] = rows["conv3x3_dgrad"].get("wino", 0) + wd
     seen = {}
     k = afdm.circularLowpassKernel(math.pi / 2, 3, 2)
     tk = ops.Taps(k)
@@ -129,10 +124,45 @@ def kernel_table(dev, B):
     out = []
     for name, r in rows.items():
         sec = r["ms"] * 1e-3
-        out.append({"kernel": name, "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 4),
+        out.append({"kernel": name, "launches_per_step": r["launches"], "winograd_launches": r.get("wino"), "ms_per_step": round(r["ms"], 4),
                     "tflops": round(r["flops"] / sec / 1e12, 3) if r["flops"] else None,
                     "gbs": round(r["bytes"] / sec / 1e9, 1) if r["bytes"] else None})
     return out, rows
+
+
+def conv_layer_times(L, s, dev, B, ci, co, S, reps=5):
+    """(fwd, dgrad, wgrad) ms of one 3x3 layer through the same dispatch the autograd shells use (ops.py): the
+    Winograd entry points where the library covers the shape (non-zero workspace), else the direct kernels.
+    Also returns whether forward / dgrad took the Winograd path."""
+    x = torch.randn(B, ci, S, S, device=dev); w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+    y = torch.randn(B, co, S, S, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
+    ws = torch.empty(max(L.afd_conv_wgrad_workspace_bytes(B, ci, co, S, S, 3) // 4, 1), device=dev)
+    nf, nd = L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, 0), L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, 1)
+    u = torch.empty(max(nf, nd, 4) // 4, device=dev)
+    if nf:
+        tf = ev_time(lambda: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, s), reps)
+    else:
+        tf = ev_time(lambda: L.afd_conv_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 3, 0, s), reps)
+    if ci <= 3:
+        td = 0.0
+    elif nd:
+        td = ev_time(lambda: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), B, ci, co, S, S, u.data_ptr(), 0, s), reps)
+    else:
+        td = ev_time(lambda: L.afd_conv_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), B, ci, co, S, S, 3, s), reps)
+    tw = ev_time(lambda: L.afd_conv_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, B, ci, co, S, S, 3, 0, ws.data_ptr(), s), reps)
+    return tf, td, tw, 1 if nf else 0, 1 if (nd and ci > 3) else 0
+
+
+def pmc_traffic(family, launches):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/pmc_families.json,
+    produced by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as the guide's
+    gfx950 correction prescribes).  None when the family has no committed pass."""
+    path = os.path.join(ROOT, "profiles", "pmc_families.json")
+    try:
+        d = json.load(open(path))[family]
+        return int(d["hbm_bytes_per_step"] / max(1, launches)), d.get("source", "profiles/pmc_families.json")
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(steps=6, B=64):
@@ -275,16 +305,21 @@ def main():
             dom = max(rows.items(), key=lambda kv: kv[1]["ms"])
             name, r = dom
             sec = r["ms"] * 1e-3
+            traffic, tsrc = pmc_traffic(name, r["launches"])
             if r["flops"]:
                 ach = r["flops"] / sec / 1e12
                 result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF,
-                                      "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None,
-                                      "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3)}
+                                      "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": traffic,
+                                      "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3),
+                                      "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+                                      "basis": "algorithmic direct-form flops (2*9*Cin*Cout per output pixel, SURVEY 8d) / HIP-event time; "
+                                               "the Winograd kernels issue 16/36 of those multiplies on the fp32 MFMA, so frac is not bounded by 1",
+                                      "traffic_source": tsrc}
             else:
                 ach = r["bytes"] / sec / 1e9
                 result["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                                      "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3)}
+                                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                      "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3), "traffic_source": tsrc}
             result["kernels"] = table
         if not args.no_cpu_baseline:
             log(f"CPU baseline on {host_threads()} host threads")

@@ -133,6 +133,10 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias /* o
  * afd_debug_conv_path: 64 / 65 = Winograd chosen by the measured rule (default) / never; 66..69 = whenever covered,
  * with workgroups of 64x64 / 32x64 / 64x32 / 32x32 (output channels x tiles). */
 size_t afd_conv3x3_wino_workspace_bytes(int B, int Cin, int Cout, int H, int W, int dgrad);
+/* the transformed weights of both passes (either pointer may be NULL) in ONE launch: the dgrad image is the forward
+ * image with permuted transform indices.  Buffers of 16*Cin*Cout floats each; afterwards call the entry points below
+ * with weights_ready = 1. */
+int afd_conv3x3_wino_weights(const float* w, float* u_fwd, float* u_dgrad, int Cin, int Cout, afd_stream_t stream);
 int afd_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
                          int B, int Cin, int Cout, int H, int W, int act, void* workspace, int weights_ready,
                          afd_stream_t stream);

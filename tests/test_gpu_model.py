@@ -156,7 +156,21 @@ def _train_setup(afdm, dev):
     return model, diff
 
 
-def test_train_step_vs_reference(A):
+@pytest.fixture
+def conv_path(A, request):
+    """'winograd' forces the Winograd kernels on every 3x3 layer they cover (at these small batches the by-rule choice
+    would keep most layers on the direct kernels); 'direct' switches them off."""
+    afdm, _ = A
+    L = afdm.lib()
+    for m in {"auto": (64, 96), "winograd": (67, 98), "direct": (65, 97)}[request.param]:
+        L.afd_debug_conv_path(m)
+    yield request.param
+    L.afd_debug_conv_path(64)
+    L.afd_debug_conv_path(96)
+
+
+@pytest.mark.parametrize("conv_path", ["auto", "winograd", "direct"], indirect=True)
+def test_train_step_vs_reference(A, conv_path):
     """ddpm_utils.py:499-507 with t / eps injected from the reference's own CPU run (B=4, Config D)."""
     afdm, dev = A
     g = load_golden("train_step.npz")
@@ -201,8 +215,9 @@ def test_graph_replay_equals_eager(A):
     assert rel_l2(outs[1][2], outs[0][2]) < 1e-6
 
 
+@pytest.mark.parametrize("conv_path", ["auto", "winograd"], indirect=True)
 @pytest.mark.parametrize("variant,c", [(3, 3), (0, 1)])
-def test_sample_100_steps_vs_reference(A, variant, c):
+def test_sample_100_steps_vs_reference(A, variant, c, conv_path):
     """Diffusion.sample / revert, T=101, replaying the reference CPU run's noise stream."""
     afdm, dev = A
     g = load_golden("sample.npz")
