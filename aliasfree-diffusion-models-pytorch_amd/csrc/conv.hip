@@ -850,7 +850,7 @@ int afd_debug_conv_path(int mode) {
   if (mode >= 100000 && mode < 200000) { wino_set_grid(mode - 100000); return AFD_OK; }   // Winograd persistent grid size (0 = default)
   if (mode >= 1000 && mode < 1064) { wino_set_dbg(mode - 1000); return AFD_OK; }   // ablation switches (tools/wino_abl.py)
   if (mode >= 96 && mode <= 98) { wgrad_wino_set_mode(mode - 96); return AFD_OK; }   // Winograd wgrad: 96 = by rule (default), 97 = off, 98 = whenever covered
-  if (mode >= 64 && mode <= 69) { wino_set_mode(mode - 64); return AFD_OK; }   // Winograd 3x3: 64 = by rule (default), 65 = off, 66..69 = forced, workgroups of 64x64 / 32x64 / 64x32 / 32x32 (channels x tiles)
+  if (mode >= 64 && mode <= 70) { wino_set_mode(mode - 64); return AFD_OK; }   // Winograd 3x3: 64 = by rule (default), 65 = off, 66..69 = forced, workgroups of 64x64 / 32x64 / 64x32 / 32x32 (channels x tiles)
   if (mode >= 32 && mode <= 34) { g_wgrad_nw = mode == 32 ? 4 : (mode == 33 ? 8 : 0); return AFD_OK; }   // wgrad waves: 4 / 8 / auto
   AFD_REQUIRE(mode >= 0 && mode <= 2, "afd_debug_conv_path: mode must be 0 (auto), 1 (big tile), 2 (split-K tile), 8..10 (1x1 streaming auto/off/forced), 32..34 (wgrad waves 4/8/auto), 64..69 (Winograd fwd/dgrad auto/off/forced shapes) or 96..98 (Winograd wgrad auto/off/forced)");
   g_conv_path = mode;

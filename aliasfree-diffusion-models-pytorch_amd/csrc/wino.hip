@@ -307,11 +307,183 @@ __global__ __launch_bounds__(BN * NT / 8, BN * NT == 4096 ? 1 : 2) void conv_win
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Small maps (4x4, 8x8): few tiles, deep reductions.  A workgroup owns 32 output channels x 16 tiles (whole images, so
+// every halo cell is a constant zero) and its FOUR WAVES SPLIT THE INPUT CHANNELS: each wave runs the whole
+// F(2x2,3x3) pipeline on its quarter of K with no workgroup barrier in the loop -- its 8 input channels of a chunk sit
+// in a wave-private LDS patch image, and its A fragments come STRAIGHT FROM GLOBAL MEMORY: in the [k/8][xi][n][8]
+// weight image the 64 lanes of a fragment read one contiguous 512-byte run.  The four partial results meet once, after
+// the (linear) output transform, through LDS.
+// ------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256, 2) void conv_wino_sk(const float* __restrict__ x, const float* __restrict__ U,
+                                                       const float* __restrict__ bias, const float* __restrict__ res,
+                                                       float* __restrict__ y, int B, int K, int N, int act) {
+  using G = WGeo<S, 16>;
+  static_assert(G::GPI == 1, "tile groups must be whole images");
+  constexpr int KC = 8, W = S, HW = S * S, Wp = G::Wp, IMG = G::IMG, RS = G::RS, RSP = G::RSP, TI = G::TI;
+  constexpr int UPC = TI * S * (S / 4);              // float4 pieces per channel (= 16)
+  static_assert(UPC == 16, "one chunk = 128 float4 pieces per wave");
+  constexpr int DEPTH = 8;                           // A fragments in flight, in units of xi
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* Rs = smem + wv * (KC * RSP);                // this wave's patch image [KC][RSP]
+  float* red = smem + 4 * KC * RSP;                  // [4 waves][32 values][64 lanes]
+  const int n0 = blockIdx.x * 32, tg = blockIdx.y, b0 = tg * TI;
+  const int li = lane & 15, lq = lane >> 4;
+  const int poff = (li / (G::TROWS * G::TPR)) * IMG + 2 * ((li / G::TPR) % G::TROWS) * Wp + 2 * (li % G::TPR);
+  const int KS = K / 4, nchunks = KS / KC, kw = wv * KS;       // this wave's channel slice
+
+  for (int i = lane; i < KC * RSP; i += 64) Rs[i] = 0.f;      // halo cells stay zero for the whole kernel
+
+  // staging: piece u = lane + 64 e (e = 0, 1): channel u / 16, float4 (u % 16) of the TI x S x S block
+  unsigned rsrc[2]; int rdst[2]; bool rok[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int u = lane + 64 * e, ch = u / UPC, q = u % UPC;
+    const int ti = q / (S * (S / 4)), rr = (q / (S / 4)) % S, x4 = q % (S / 4);
+    rok[e] = b0 + ti < B;
+    rsrc[e] = rok[e] ? (unsigned)(((b0 + ti) * K + kw + ch) * HW + rr * W + 4 * x4) : 0u;
+    rdst[e] = ch * RSP + ti * IMG + (rr + 1) * Wp + 1 + 4 * x4;
+  }
+  f32x4 rreg[2];
+  auto fetch = [&](int c) {
+    const float* xk = x + (long)c * KC * HW;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) rreg[e] = *reinterpret_cast<const f32x4*>(xk + rsrc[e]);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      float* d = Rs + rdst[e];
+      const bool ok = rok[e];
+      d[0] = ok ? rreg[e][0] : 0.f; d[1] = ok ? rreg[e][1] : 0.f; d[2] = ok ? rreg[e][2] : 0.f; d[3] = ok ? rreg[e][3] : 0.f;
+    }
+  };
+  auto patch = [&](int k, float (&v)[16]) {
+    const float* r = Rs + k * RSP + poff;
+    float d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float2 lo = *reinterpret_cast<const float2*>(r + a * Wp);
+      const float2 hi = *reinterpret_cast<const float2*>(r + a * Wp + 2);
+      d[a][0] = lo.x; d[a][1] = lo.y; d[a][2] = hi.x; d[a][3] = hi.y;
+    }
+    float w[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      w[0][j] = d[0][j] - d[2][j];
+      w[1][j] = d[1][j] + d[2][j];
+      w[2][j] = d[2][j] - d[1][j];
+      w[3][j] = d[1][j] - d[3][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[4 * i + 0] = w[i][0] - w[i][2];
+      v[4 * i + 1] = w[i][1] + w[i][2];
+      v[4 * i + 2] = w[i][2] - w[i][1];
+      v[4 * i + 3] = w[i][1] - w[i][3];
+    }
+  };
+  // A fragment of (chunk c, xi): U[(kw/8 + c)][xi][n0 + li (+16)][2 lq .. 2 lq + 1]; the lanes of one load cover 512 B
+  const float* ua = U + ((long)(kw / KC) * 16 * N + n0 + li) * 8 + 2 * lq;
+  const long xstep = (long)N * 8;                    // one xi plane
+  const int total = nchunks * 16;                    // flat (chunk, xi) index g = 16 c + xi
+  f32x2 abuf[DEPTH][2];
+  auto aload = [&](int g, int slot) {
+    const float* p = ua + (long)g * xstep;           // (chunk c, xi) planes are consecutive: (16 c + xi) * N * 8
+    abuf[slot][0] = *reinterpret_cast<const f32x2*>(p);
+    abuf[slot][1] = *reinterpret_cast<const f32x2*>(p + 128);
+  };
+
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[xi][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int g = 0; g < DEPTH; ++g) aload(g, g);       // (total >= 16 > DEPTH)
+  fetch(0);
+  for (int c = 0; c < nchunks; ++c) {
+    commit();                                        // wave-private image: program order is the only ordering needed
+    if (c + 1 < nchunks) fetch(c + 1);
+    float v0[16], v1[16];
+    patch(lq, v0);
+    patch(lq + 4, v1);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+      const f32x2 lo = abuf[xi % DEPTH][0], hi = abuf[xi % DEPTH][1];
+      const int gn = c * 16 + xi + DEPTH;
+      if (gn < total) aload(gn, xi % DEPTH);
+      __builtin_amdgcn_sched_barrier(0);             // keep the refill above the multiplies
+      acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(lo[0], v0[xi], acc[xi][0], 0, 0, 0);
+      acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(hi[0], v0[xi], acc[xi][1], 0, 0, 0);
+      acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(lo[1], v1[xi], acc[xi][0], 0, 0, 0);
+      acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(hi[1], v1[xi], acc[xi][1], 0, 0, 0);
+    }
+  }
+
+  // ---- output transform of the wave's partial sums (linear, so it commutes with the cross-wave sum), then the four
+  // partials meet in LDS: value index j = (h*4 + r)*4 + {y00, y01, y10, y11}
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float tcol[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float m0 = acc[4 * i + 0][h][r], m1 = acc[4 * i + 1][h][r], m2 = acc[4 * i + 2][h][r], m3 = acc[4 * i + 3][h][r];
+        tcol[i][0] = (m0 + m1) + m2;
+        tcol[i][1] = (m1 - m2) - m3;
+      }
+      float* o = red + ((wv * 32 + (h * 4 + r) * 4) * 64) + lane;
+      o[0] = (tcol[0][0] + tcol[1][0]) + tcol[2][0];
+      o[64] = (tcol[0][1] + tcol[1][1]) + tcol[2][1];
+      o[128] = (tcol[1][0] - tcol[2][0]) - tcol[3][0];
+      o[192] = (tcol[1][1] - tcol[2][1]) - tcol[3][1];
+    }
+  __syncthreads();
+  // wave w finishes the (h, r) pairs 2w and 2w + 1 (fixed summation order: deterministic)
+  const int ob = b0 + li / (G::TROWS * G::TPR);
+  if (ob >= B) return;
+  const int opix = 2 * ((li / G::TPR) % G::TROWS) * W + 2 * (li % G::TPR);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int hr = 2 * wv + e, h = hr >> 2, r = hr & 3;
+    float yv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* q = red + (hr * 4 + j) * 64 + lane;
+      yv[j] = (q[0] + q[32 * 64]) + (q[2 * 32 * 64] + q[3 * 32 * 64]);
+    }
+    const int n = n0 + 16 * h + 4 * lq + r;
+    const unsigned idx = (unsigned)((ob * N + n) * HW + opix);
+    if (bias) { const float bb = bias[n]; yv[0] += bb; yv[1] += bb; yv[2] += bb; yv[3] += bb; }
+    if (act == 1) { yv[0] = gelu_erf(yv[0]); yv[1] = gelu_erf(yv[1]); yv[2] = gelu_erf(yv[2]); yv[3] = gelu_erf(yv[3]); }
+    if (res) {
+      const float2 r0 = *reinterpret_cast<const float2*>(res + idx), r1 = *reinterpret_cast<const float2*>(res + idx + W);
+      yv[0] += r0.x; yv[1] += r0.y; yv[2] += r1.x; yv[3] += r1.y;
+    }
+    *reinterpret_cast<float2*>(y + idx) = make_float2(yv[0], yv[1]);
+    *reinterpret_cast<float2*>(y + idx + W) = make_float2(yv[2], yv[3]);
+  }
+}
+
+template <int S>
+static void wino_sk_launch(const float* x, const float* U, const float* bias, const float* res, float* y, int B, int K, int N, int act,
+                           hipStream_t s) {
+  using G = WGeo<S, 16>;
+  const size_t lds = sizeof(float) * (4 * 8 * G::RSP + 4 * 32 * 64);
+  const int tg = (B + G::TI - 1) / G::TI;
+  hipLaunchKernelGGL((conv_wino_sk<S>), dim3(N / 32, tg), dim3(256), lds, s, x, U, bias, res, y, B, K, N, act);
+}
+
 static int g_wino_grid = 0;      // test / tuning hook: persistent grid size (0 = fill the chip once)
 void wino_set_grid(int g) { g_wino_grid = g; }
 static int g_wino_dbg = 0;
 void wino_set_dbg(int d) { g_wino_dbg = d; }
-static int g_wino_mode = 0;        // 0 = by rule, 1 = off, 2..5 = whenever the shape is supported: workgroups of 64x64, 32x64, 64x32, 32x32 (channels x tiles)
+static int g_wino_mode = 0;        // 0 = by rule, 1 = off, 2..5 = whenever the shape is supported: workgroups of 64x64, 32x64, 64x32, 32x32 (channels x tiles); 6 = the small-map split-K kernel wherever covered
 void wino_set_mode(int m) { g_wino_mode = m; }
 
 // workgroup shape for a Winograd launch: BN * 256 + NT, or 0 when the layer stays on the direct kernel
@@ -329,6 +501,9 @@ int wino_plan(int B, int K, int N, int H, int W) {
   // transform shared by two channel blocks) is best once it gives every CU a workgroup; below that 32 x 64 (two
   // workgroups per CU); Winograd wins from 4 chunks up; the 4x4 maps (4 tiles per image) and thin launches stay direct
   const long tiles = (long)B * (H / 2) * (W / 2);
+  if (g_wino_mode == 6) return (W <= 8 && K % 32 == 0 && K >= 64) ? 1 : 0;       // (tests) the small-map kernel wherever covered
+  // 4x4 and 8x8 maps whose launch cannot give every CU a 64-tile workgroup: the in-workgroup split-K kernel
+  if (W <= 8 && K % 32 == 0 && K >= 64 && !(n64 && (tiles / 64) * (N / 64) >= 256) && (tiles / 16) * (N / 32) >= 128) return 1;
   if (K < 32 || W < 8) return 0;
   if (n64 && (tiles / 64) * (N / 64) >= 256) return 64 * 256 + 64;
   if ((tiles / 64) * (N / 32) >= 256) return 32 * 256 + 64;
@@ -364,6 +539,12 @@ bool wino_conv(const float* x, const float* w, const float* bias, const float* r
   if (!plan || !U) return false;
   const int bn = plan >> 8, nt = plan & 255;
   const int Cin = dgrad ? N : K, Cout = dgrad ? K : N;
+  if (plan == 1) {
+    if (!weights_ready)
+      hipLaunchKernelGGL(wino_weights, dim3((unsigned)((K * N + 255) / 256)), dim3(256), 0, s, w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout);
+    if (W == 4) wino_sk_launch<4>(x, U, bias, res, y, B, K, N, act, s); else wino_sk_launch<8>(x, U, bias, res, y, B, K, N, act, s);
+    return true;
+  }
   if (!weights_ready && !(g_wino_dbg & 32))
     hipLaunchKernelGGL(wino_weights, dim3((unsigned)((K * N + 255) / 256)), dim3(256), 0, s, w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout);
 #define AFD_WINO(GEO_)                                                                            \

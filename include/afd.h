@@ -131,7 +131,8 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias /* o
  * forward and the dgrad forms differ); weights_ready != 0 says it still holds them from an earlier call with the
  * same w and the same pass, so the transform launch is skipped (sampling: w is constant over the 999 steps).
  * afd_debug_conv_path: 64 / 65 = Winograd chosen by the measured rule (default) / never; 66..69 = whenever covered,
- * with workgroups of 64x64 / 32x64 / 64x32 / 32x32 (output channels x tiles). */
+ * with workgroups of 64x64 / 32x64 / 64x32 / 32x32 (output channels x tiles); 70 = the small-map (4x4, 8x8)
+ * in-workgroup split-K kernel wherever it is covered. */
 size_t afd_conv3x3_wino_workspace_bytes(int B, int Cin, int Cout, int H, int W, int dgrad);
 /* the transformed weights of both passes (either pointer may be NULL) in ONE launch: the dgrad image is the forward
  * image with permuted transform indices.  Buffers of 16*Cin*Cout floats each; afterwards call the entry points below

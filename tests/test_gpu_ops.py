@@ -202,15 +202,17 @@ CONV_CASES = [
     (5, 128, 64, 8, 8, 3, False, False),      # Winograd: four images per tile group, ragged last group
     (2, 64, 32, 16, 16, 3, True, True),       # Winograd epilogue: bias + residual (+ GELU in the no-grad form)
     (3, 8, 96, 16, 16, 3, False, False),      # Winograd: one chunk, three 32-channel blocks
+    (6, 64, 96, 4, 4, 3, True, True),         # small-map split-K Winograd: 4 images per group, ragged last group, epilogue
+    (3, 128, 32, 8, 8, 3, False, False),      # small-map split-K Winograd: one 8x8 image per group
 ]
 
 
-@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "nowino", "wgwino", "nowgwino"])
+@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "winosk", "nowino", "wgwino", "nowgwino"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[5]}" for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(A, case, path):
     afdm, ops, dev = A
     afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10,
-                                        "wino64x64": 66, "wino32x64": 67, "wino64x32": 68, "wino32x32": 69, "nowino": 65, "wgwino": 98, "nowgwino": 97}[path])
+                                        "wino64x64": 66, "wino32x64": 67, "wino64x32": 68, "wino32x32": 69, "winosk": 70, "nowino": 65, "wgwino": 98, "nowgwino": 97}[path])
     try:
         _conv_case(ops, dev, case)
     finally:

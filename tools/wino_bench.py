@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L, s = afdm.lib(), torch.cuda.current_stream().cuda_stream
 shapes = sorted(set(bench.CONV3), key=lambda t: (-t[2], t[0], t[1]))
-print(f"{'shape':>20} {'n':>2} {'GFLOP':>6} | {'dir fwd':>8} {'64x64':>8} {'32x64':>8} {'64x32':>8} {'32x32':>8} {'auto':>8} | {'dir dgr':>8} {'64x64':>8} {'32x64':>8} {'64x32':>8} {'32x32':>8} {'auto':>8}   (us)")
+print(f"{'shape':>20} {'n':>2} {'GFLOP':>6} | {'dir fwd':>8} {'64x64':>8} {'32x64':>8} {'64x32':>8} {'splitK':>8} {'auto':>8} | {'dir dgr':>8} {'64x64':>8} {'32x64':>8} {'64x32':>8} {'splitK':>8} {'auto':>8}   (us)")
 tot = {"dir": 0.0, "auto": 0.0}
 for (ci, co, S) in shapes:
     if ci < 8:
@@ -30,7 +30,7 @@ for (ci, co, S) in shapes:
             else: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, s)
         td = bench.ev_time(direct, reps=10)
         ts = []
-        for mode in (66, 67, 68, 69, 64):
+        for mode in (66, 67, 68, 70, 64):
             L.afd_debug_conv_path(mode)
             if L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, dgrad):
                 ts.append(bench.ev_time(wino, reps=10))
