@@ -53,10 +53,13 @@ __device__ __forceinline__ int kperm8(int k) { return 2 * (k & 3) + (k >> 2); } 
 // permuted: no second transform.
 __global__ __launch_bounds__(256) void wino_weights(const float* __restrict__ w, float* __restrict__ Uf, float* __restrict__ Ud,
                                                     int Cin, int Cout) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Cin * Cout) return;
-  const int ci = idx % Cin, co = idx / Cin;
-  const float* p = w + (long)idx * 9;
+  // a wave = one 8 x 8 block (8 output x 8 input channels): in BOTH images the 64 values of a transform index form one
+  // contiguous 256-byte run, so every store is coalesced
+  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int nci8 = Cin >> 3;
+  if (blk >= nci8 * (Cout >> 3)) return;
+  const int ci = (blk % nci8) * 8 + (lane & 7), co = (blk / nci8) * 8 + (lane >> 3);
+  const float* p = w + ((long)co * Cin + ci) * 9;
   float g[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) g[t] = p[t];
@@ -541,12 +544,12 @@ bool wino_conv(const float* x, const float* w, const float* bias, const float* r
   const int Cin = dgrad ? N : K, Cout = dgrad ? K : N;
   if (plan == 1) {
     if (!weights_ready)
-      hipLaunchKernelGGL(wino_weights, dim3((unsigned)((K * N + 255) / 256)), dim3(256), 0, s, w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout);
+      hipLaunchKernelGGL(wino_weights, dim3((unsigned)((K * N / 64 + 3) / 4)), dim3(256), 0, s, w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout);
     if (W == 4) wino_sk_launch<4>(x, U, bias, res, y, B, K, N, act, s); else wino_sk_launch<8>(x, U, bias, res, y, B, K, N, act, s);
     return true;
   }
   if (!weights_ready && !(g_wino_dbg & 32))
-    hipLaunchKernelGGL(wino_weights, dim3((unsigned)((K * N + 255) / 256)), dim3(256), 0, s, w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout);
+    hipLaunchKernelGGL(wino_weights, dim3((unsigned)((K * N / 64 + 3) / 4)), dim3(256), 0, s, w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout);
 #define AFD_WINO(GEO_)                                                                            \
   if (bn == 64 && nt == 64) wino_launch_t<GEO_, 64, 64>(x, U, bias, res, y, B, K, N, act, s);     \
   else if (bn == 32 && nt == 64) wino_launch_t<GEO_, 32, 64>(x, U, bias, res, y, B, K, N, act, s); \
@@ -803,7 +806,7 @@ int wgrad_wino(const float* x, const float* dy, float* part, int B, int Cin, int
 
 // both (or either) transformed-weight images of a layer in one launch
 void wino_weights_launch(const float* w, float* Uf, float* Ud, int Cin, int Cout, hipStream_t s) {
-  hipLaunchKernelGGL(wino_weights, dim3((unsigned)((Cin * Cout + 255) / 256)), dim3(256), 0, s, w, Uf, Ud, Cin, Cout);
+  hipLaunchKernelGGL(wino_weights, dim3((unsigned)((Cin * Cout / 64 + 3) / 4)), dim3(256), 0, s, w, Uf, Ud, Cin, Cout);
 }
 
 }  // namespace afd
