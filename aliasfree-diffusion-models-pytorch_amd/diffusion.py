@@ -126,6 +126,7 @@ class Diffusion:
         if theta is not None:
             logging.info(f"Theta {theta} provided. Rotation will be applied.")
         x, snaps = self._loop(model, n, image_channels, theta, noise_source, graph)
+        self.last_float_snapshots = snaps          # pre-quantisation x at i % 100 == 0 and the final x (parity tests)
         xq = ops.quantize_u8(x)
         rq = ops.quantize_u8(torch.cat(snaps))
         if return_float:

@@ -349,6 +349,37 @@ def gen_sample(rm, rutil):
     save("sample.npz", **out)
 
 
+def gen_sample_full(rm, rutil):
+    """The reference's full-length run: Diffusion.sample with T=1000 (999 denoise steps), Config D, c=3, n=2, on CPU,
+    noise from the torch CPU generator under set_seed(7) as in gen_sample().  Stores the uint8 outputs and the
+    pre-quantisation float x at i = 900, 500, 100 and 1 (hand replay of ddpm_models.py:367-374, checked against
+    Diffusion.sample's own uint8 result)."""
+    out = {}
+    variant, c = 3, 3
+    rutil.set_seed(42)
+    model = rm.UNet(c_in=c, c_out=c, image_size=32, f_settings=dict(F_SET), device="cpu", variant=variant)
+    diff = rm.Diffusion(noise_steps=1000, img_size=32, device="cpu")
+    rutil.set_seed(7)
+    x, result = diff.sample(model, n=2, image_channels=c)
+    out["sample_x"], out["sample_result"] = n(x), n(result)
+    rutil.set_seed(7)
+    with torch.no_grad():
+        model.eval()
+        xx = torch.randn((2, c, 32, 32))
+        for i in reversed(range(1, 1000)):
+            t = (torch.ones(2) * i).long()
+            eps = model(xx, t)
+            a, ah, b = diff.alpha[t][:, None, None, None], diff.alpha_hat[t][:, None, None, None], diff.beta[t][:, None, None, None]
+            nz = torch.randn_like(xx) if i > 1 else torch.zeros_like(xx)
+            xx = 1 / torch.sqrt(a) * (xx - ((1 - a) / (torch.sqrt(1 - ah))) * eps) + torch.sqrt(b) * nz
+            if i in (900, 500, 100, 1):
+                out[f"float_x_after_i{i}"] = n(xx.clone())
+        model.train()
+    hand = (((xx.clamp(-1, 1) + 1) / 2) * 255).type(torch.uint8)
+    assert torch.equal(hand, x), "hand replay diverged from Diffusion.sample"
+    save("sample_full.npz", **out)
+
+
 def main():
     torch.set_num_threads(8)
     rf, ru, rm, rutil = _import_reference()
@@ -367,6 +398,8 @@ def main():
         gen_train_step(rm, rutil)
     if "sample" in which:
         gen_sample(rm, rutil)
+    if "sample_full" in which:                  # ~10 minutes of CPU: not part of the default set
+        gen_sample_full(rm, rutil)
     assert not os.path.exists(os.path.join(REF, "modules", "__pycache__")), "reference tree was written to"
 
 

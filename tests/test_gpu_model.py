@@ -246,6 +246,27 @@ def test_sample_100_steps_vs_reference(A, variant, c, conv_path):
         assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.02
 
 
+def test_sample_999_steps_vs_reference(A):
+    """SURVEY 8d gate: the FULL-length trajectory (T=1000, 999 UNet evaluations, Config D, c=3, n=2), replaying the
+    reference CPU run's noise stream; pre-quantisation x within 1e-4 relative L2 at i = 900, 500, 100 and 1."""
+    afdm, dev = A
+    g = load_golden("sample_full.npz")
+    afdm.set_seed(42)
+    model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device=dev, variant=3).to(dev)
+    diff = afdm.Diffusion(noise_steps=1000, img_size=32, device=dev)
+    afdm.set_seed(7)
+    xq, rq, xf = diff.sample(model, n=2, image_channels=3, noise_source="cpu", return_float=True)
+    fs = diff.last_float_snapshots                 # x after i = 900, 800, ..., 100, then the final x
+    snaps = {900: fs[0], 500: fs[4], 100: fs[8], 1: xf}
+    for i in (900, 500, 100, 1):
+        err = rel_l2(snaps[i].cpu(), g[f"float_x_after_i{i}"])
+        print(f"999-step sample, after i={i}: rel-L2 {err:.3e}")
+        assert err < 1e-4, i
+    for got, want in ((xq, g["sample_x"]), (rq, g["sample_result"])):
+        d = got.cpu().numpy().astype(int) - want.astype(int)
+        assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.01
+
+
 def test_graph_sampling_equals_eager_sampling(A):
     """One captured denoise step replayed T-2 times must equal the eager loop (same device RNG seed)."""
     afdm, dev = A
