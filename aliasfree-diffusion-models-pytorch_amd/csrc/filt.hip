@@ -145,6 +145,61 @@ __global__ void gelu_grad_mul_gen(const float* __restrict__ u, float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// exact-GELU by table: the fused kernels are bound by vector instructions (4 GELUs per element), and the rcp + exp
+// form of erf costs ~19 of them.  Both GELU(u) = u (1/2 + e(|u|) sgn u) and GELU'(u) = 1/2 + h(|u|) sgn u are an odd
+// function of u around 1/2: e(a) = Phi(a) - 1/2, h(a) = e(a) + a phi(a).  Each is tabulated on [0, 6) as 96 cubic
+// Hermite pieces of width 1/16 (coefficients from fp64 erf / exp: interpolation error <= 2.2e-8 and 1.2e-7, below the
+// 6e-7 of the A&S form it replaces; beyond 6 both are 1/2 to 4e-8), copied to LDS by every workgroup: a lookup is one
+// ds_read_b128 (neighbouring pixels mostly hit the same piece: broadcast) + 3 fma, ~11 vector instructions per GELU.
+// The table is produced ON THE DEVICE by a one-thread-per-piece kernel at first use -- a launch, so it is legal under
+// stream capture and allocates nothing (static device storage).
+// ------------------------------------------------------------------------------------------
+constexpr int kGeluPieces = 96;
+constexpr float kGeluScale = 16.f;
+__device__ float4 g_gelu_tab[2 * kGeluPieces];        // [0, 96): e pieces; [96, 192): h pieces
+
+__global__ void gelu_table_init() {
+  const int i = threadIdx.x;
+  if (i >= kGeluPieces) return;
+  const double hstep = 1.0 / 16.0, a0 = i * hstep, a1 = a0 + hstep;
+  const double isq2 = 0.70710678118654752440, isq2pi = 0.39894228040143267794;
+  auto phi = [&](double a) { return isq2pi * exp(-0.5 * a * a); };
+  auto e = [&](double a) { return 0.5 * erf(a * isq2); };
+  auto hfun = [&](double a) { return e(a) + a * phi(a); };
+  auto hder = [&](double a) { return (2.0 - a * a) * phi(a); };
+  {
+    const double f0 = e(a0), f1 = e(a1), d0 = hstep * phi(a0), d1 = hstep * phi(a1);
+    g_gelu_tab[i] = make_float4((float)f0, (float)d0, (float)(3.0 * (f1 - f0) - 2.0 * d0 - d1), (float)(2.0 * (f0 - f1) + d0 + d1));
+  }
+  {
+    const double f0 = hfun(a0), f1 = hfun(a1), d0 = hstep * hder(a0), d1 = hstep * hder(a1);
+    g_gelu_tab[kGeluPieces + i] = make_float4((float)f0, (float)d0, (float)(3.0 * (f1 - f0) - 2.0 * d0 - d1), (float)(2.0 * (f0 - f1) + d0 + d1));
+  }
+}
+static void ensure_gelu_table(hipStream_t s) {
+  static bool done = false;
+  if (done) return;
+  hipLaunchKernelGGL(gelu_table_init, dim3(1), dim3(128), 0, s);
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  // a captured launch only runs at replay: keep launching (12 us once per call) until one eager launch has happened
+  if (hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusNone) done = true;
+}
+// odd-part lookup: T[piece](t), piece = floor(16 |u|) clamped, t = frac
+__device__ __forceinline__ float gelu_odd_part(float u, const float4* __restrict__ T) {
+  const float sx = fminf(fabsf(u) * kGeluScale, (float)kGeluPieces - 0.001f);
+  const float4 c = T[(int)sx];
+  const float t = __builtin_amdgcn_fractf(sx);
+  const float v = fmaf(fmaf(fmaf(c.w, t, c.z), t, c.y), t, c.x);
+  return copysignf(v, u);
+}
+__device__ __forceinline__ float gelu_tab(float u, const float4* __restrict__ T) { return fmaf(u, gelu_odd_part(u, T), 0.5f * u); }
+__device__ __forceinline__ float gelu_grad_tab(float u, const float4* __restrict__ T) { return 0.5f + gelu_odd_part(u, T + kGeluPieces); }
+__device__ __forceinline__ void load_gelu_table(float4* __restrict__ T, int first, int count) {   // 256-thread workgroups
+  if ((int)threadIdx.x < count) T[threadIdx.x] = g_gelu_tab[first + threadIdx.x];
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
 // fast path, N == 3, S x S planes.  lane = (plane slot, column)
 // ------------------------------------------------------------------------------------------
 template <int S>
@@ -220,6 +275,8 @@ __global__ __launch_bounds__(256) void filt_act_fwd_n3(const float* __restrict__
                                                        long planes, int C, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ res, Taps3 u, Taps3 d) {
+  __shared__ float4 T[kGeluPieces];
+  load_gelu_table(T, 0, kGeluPieces);
   Lane<S> L(planes);
   const long b = L.plane / C; const int c = L.plane % C;
   const long base = L.plane * (long)S * S + L.col;
@@ -235,10 +292,10 @@ __global__ __launch_bounds__(256) void filt_act_fwd_n3(const float* __restrict__
   for (int i = 0; i < S; ++i) {
     const float xe = xv[i], xd = xv[i + 1];
     const float xdr = L.right(xd);
-    const float g00 = gelu_erf(u.k[4] * xe);
-    const float g01 = gelu_erf(u.k[3] * xe + u.k[5] * xr);
-    const float g10 = gelu_erf(u.k[1] * xe + u.k[7] * xd);
-    const float g11 = gelu_erf(u.k[0] * xe + u.k[2] * xr + u.k[6] * xd + u.k[8] * xdr);
+    const float g00 = gelu_tab(u.k[4] * xe, T);
+    const float g01 = gelu_tab(u.k[3] * xe + u.k[5] * xr, T);
+    const float g10 = gelu_tab(u.k[1] * xe + u.k[7] * xd, T);
+    const float g11 = gelu_tab(u.k[0] * xe + u.k[2] * xr + u.k[6] * xd + u.k[8] * xdr, T);
     const float g01l = L.left(g01), g11l = L.left(g11);
     const float out = d.k[0] * g11lp + d.k[1] * g10p + d.k[2] * g11p
                     + d.k[3] * g01l  + d.k[4] * g00  + d.k[5] * g01
@@ -260,6 +317,9 @@ __global__ __launch_bounds__(256) void filt_act_bwd_n3(const float* __restrict__
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ res,
                                                        float* __restrict__ part, Taps3 u, Taps3 d) {
+  __shared__ float4 Tb[2 * kGeluPieces];
+  load_gelu_table(Tb, 0, 2 * kGeluPieces);
+  const float4* T = Tb;
   Lane<S> L(planes);
   const long b = L.plane / C; const int c = L.plane % C;
   const long base = L.plane * (long)S * S + L.col;
@@ -290,10 +350,10 @@ __global__ __launch_bounds__(256) void filt_act_bwd_n3(const float* __restrict__
     const float U01 = u.k[3] * xe + u.k[5] * xr;
     const float U10 = u.k[1] * xe + u.k[7] * xd;
     const float U11 = u.k[0] * xe + u.k[2] * xr + u.k[6] * xd + u.k[8] * xdr;
-    const float dU00 = (d.k[4] * ge) * gelu_erf_grad(U00);
-    const float dU01 = (d.k[5] * ge + d.k[3] * gr) * gelu_erf_grad(U01);
-    const float dU10 = (d.k[7] * ge + d.k[1] * gd) * gelu_erf_grad(U10);
-    const float dU11 = (d.k[8] * ge + d.k[6] * gr + d.k[2] * gd + d.k[0] * gdr) * gelu_erf_grad(U11);
+    const float dU00 = (d.k[4] * ge) * gelu_grad_tab(U00, T);
+    const float dU01 = (d.k[5] * ge + d.k[3] * gr) * gelu_grad_tab(U01, T);
+    const float dU10 = (d.k[7] * ge + d.k[1] * gd) * gelu_grad_tab(U10, T);
+    const float dU11 = (d.k[8] * ge + d.k[6] * gr + d.k[2] * gd + d.k[0] * gdr) * gelu_grad_tab(U11, T);
     const float dU01l = L.left(dU01), dU11l = L.left(dU11);
     const float out = u.k[0] * dU11 + u.k[1] * dU10 + u.k[2] * dU11l
                     + u.k[3] * dU01 + u.k[4] * dU00 + u.k[5] * dU01l
@@ -440,6 +500,7 @@ int afd_filt_act_fwd(const float* x, float* y, int B, int C, int H, int W,
   const long planes = (long)B * C;
   if (N == 3 && fast_side(H, W)) {
     const Taps3 u = load_taps3(taps_up), d = load_taps3(taps_down);
+    ensure_gelu_table(s);
     AFD_DISPATCH_S(H, filt_act_fwd_n3, fast_grid(planes, H), dim3(256), 0, s, x, y, planes, C, stats, gamma, beta, res, u, d);
     return check_launch("afd_filt_act_fwd");
   }
@@ -465,6 +526,7 @@ int afd_filt_act_bwd(const float* x, const float* dy, float* dv, int B, int C, i
   if (N == 3 && fast_side(H, W)) {
     const Taps3 u = load_taps3(taps_up), d = load_taps3(taps_down);
     AFD_REQUIRE(!gn_partials || stats, "afd_filt_act_bwd: gn_partials needs stats");
+    ensure_gelu_table(s);
     AFD_DISPATCH_S(H, filt_act_bwd_n3, fast_grid(planes, H), dim3(256), 0, s, x, dy, dv, planes, C, stats, gamma, beta, res, gn_partials, u, d);
     return check_launch("afd_filt_act_bwd");
   }
