@@ -322,11 +322,15 @@ def test_layernorm_c(A, shape):
         assert rel_l2(a.cpu(), b) < 3e-5
 
 
-@pytest.mark.parametrize("cfg", [(2, 4, 8, 1024), (2, 4, 8, 256), (3, 4, 16, 256), (2, 4, 32, 64), (5, 4, 32, 16),
+@pytest.mark.parametrize("cfg", [(2, 4, 8, 1024), (2, 4, 8, 256), (3, 2, 8, 512), (3, 4, 16, 256), (2, 4, 32, 64), (5, 4, 32, 16),
                                  (2, 4, 16, 64), (2, 2, 8, 100), (1, 4, 64, 48)])
-def test_attention_core(A, cfg):
-    _, ops, dev = A
+@pytest.mark.parametrize("fused", [True, False])
+def test_attention_core(A, cfg, fused):
+    afdm, ops, dev = A
     B, heads, d, L = cfg
+    if fused and not (d == 8 and L in (256, 512, 1024)):
+        pytest.skip("the one-pass backward only exists for d = 8, L in {256, 512, 1024}")
+    afdm.lib().afd_debug_attn_rows(9 if fused else 8)
     C = heads * d
     g = _g(L + d)
     qkv = torch.randn(B, 3 * C, L, 1, generator=g)
@@ -340,6 +344,7 @@ def test_attention_core(A, cfg):
     qd = qkv.to(dev).requires_grad_(True)
     yd = ops.Attention.apply(qd, heads)
     (gd,) = torch.autograd.grad(yd, qd, dy.to(dev))
+    afdm.lib().afd_debug_attn_rows(8)
     assert rel_l2(yd.detach().cpu(), yo.detach()) < TOL
     assert rel_l2(gd.cpu(), go) < 2e-5
 
