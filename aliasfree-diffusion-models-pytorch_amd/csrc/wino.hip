@@ -149,37 +149,39 @@ __global__ __launch_bounds__(BN * NT / 8, BN * NT == 4096 ? 1 : 2) void conv_win
   const int tt = wt * 16 + li;
   const int poff = (tt / (G::TROWS * G::TPR)) * IMG + 2 * ((tt / G::TPR) % G::TROWS) * Wp + 2 * (tt % G::TPR);
 
-  float rreg[NPOS][KC];
-  f32x4 ureg[NUV];
-  unsigned rcommit = 0;                              // validity bits of the positions held in rreg
-  auto fetch = [&](int c) {
+  // two register sets: the loads of chunk c+2 are issued right after chunk c+1 left its set for LDS, i.e. every load
+  // has TWO chunk periods to land (one period is about the loaded-chip memory latency: with a single set the waves
+  // parked on s_waitcnt for a fifth of their time)
+  struct Regs { float r[NPOS][KC]; f32x4 u[NUV]; unsigned ok; };
+  Regs S0, S1;
+  auto fetch = [&](Regs& S, int c) {
     const float* __restrict__ xk = x + (long)c * KC * HW;
     const float* __restrict__ uk = U + (long)c * 16 * N * 8;
 #pragma unroll
-    for (int e = 0; e < NUV; ++e) ureg[e] = *reinterpret_cast<const f32x4*>(uk + e * ustep + usrc0);
+    for (int e = 0; e < NUV; ++e) S.u[e] = *reinterpret_cast<const f32x4*>(uk + e * ustep + usrc0);
 #pragma unroll
     for (int e = 0; e < NPOS; ++e)
       if (tid + NTH * e < RS) {
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) rreg[e][kc] = (xk + kc * HW)[rsrc[e]];      // scalar base per channel, one lane offset
+        for (int kc = 0; kc < KC; ++kc) S.r[e][kc] = (xk + kc * HW)[rsrc[e]];      // scalar base per channel, one lane offset
       }
-    rcommit = rvalid;
+    S.ok = rvalid;
   };
-  auto commit = [&](int stage) {
+  auto commit = [&](const Regs& S, int stage) {
     float* Us = smem + stage * BUF;
     float* Rs = Us + 16 * BN * SU;
 #pragma unroll
     for (int e = 0; e < NUV; ++e) {
       float2* d = reinterpret_cast<float2*>(Us + udst0 + e * (XSTEP * 16 * SU));
-      d[0] = make_float2(ureg[e][0], ureg[e][1]);
-      d[1] = make_float2(ureg[e][2], ureg[e][3]);
+      d[0] = make_float2(S.u[e][0], S.u[e][1]);
+      d[1] = make_float2(S.u[e][2], S.u[e][3]);
     }
 #pragma unroll
     for (int e = 0; e < NPOS; ++e)
       if (tid + NTH * e < RS) {
-        const bool ok = (rcommit >> e) & 1u;
+        const bool ok = (S.ok >> e) & 1u;
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) Rs[kc * RSP + tid + NTH * e] = ok ? rreg[e][kc] : 0.f;
+        for (int kc = 0; kc < KC; ++kc) Rs[kc * RSP + tid + NTH * e] = ok ? S.r[e][kc] : 0.f;
       }
   };
   // V = B^T d B for one 4x4 patch; B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
@@ -215,27 +217,18 @@ __global__ __launch_bounds__(BN * NT / 8, BN * NT == 4096 ? 1 : 2) void conv_win
   const int o_ti = tt / (G::TROWS * G::TPR), o_ty = (tt / G::TPR) % G::TROWS, o_tx = tt % G::TPR;
   const int nchunks = K / KC;
 
-  // ---- persistent loop over work items: the workgroup walks items blockIdx.x, + gridDim.x, ...; the first chunk of the
-  // next item is fetched under the last chunk of this one and the output stores drain under the next item's multiplies
-  int w = blockIdx.x;
-  if (w >= items) return;
-  plan(w);
-  fetch(0);
-  for (; w < items; w += gridDim.x) {
+  // ---- loop over work items (one per workgroup by default; the grid may be smaller: tools)
+  for (int w = blockIdx.x; w < items; w += gridDim.x) {
+    plan(w);
+    fetch(S0, 0);
+    if (nchunks > 1) fetch(S1, 1);
     f32x4 acc[16][2];
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
       for (int h = 0; h < 2; ++h) acc[xi][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // stage 0 <- chunk 0 (fetched by the previous item's tail or the prologue); chunk 1 in flight
-    __syncthreads();                                    // (the previous item's last multiplies are done with stage 0)
-    commit(0);
-    if (nchunks > 1) fetch(1);
-    else if (w + (int)gridDim.x < items) { plan(w + gridDim.x); fetch(0); }
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-      const int st = c & 1;
+    auto multiply = [&](int st) {
       const float* Rc = Rs + st * BUF;
       const unsigned apc = ap + (unsigned)(st * BUF * 4);
       // A fragments run one xi ahead of the multiplies (the first pair is in flight under the transform)
@@ -266,12 +259,25 @@ __global__ __launch_bounds__(BN * NT / 8, BN * NT == 4096 ? 1 : 2) void conv_win
         acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(lo[1], v1[xi], acc[xi][0], 0, 0, 0);
         acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(hi[1], v1[xi], acc[xi][1], 0, 0, 0);
       }
-      // chunk c+1 (in registers since one chunk ago) -> the other stage, while slower waves still multiply chunk c
-      if (c + 1 < nchunks) {
-        commit(st ^ 1);
-        if (c + 2 < nchunks) fetch(c + 2);
-        else if (w + (int)gridDim.x < items) { plan(w + gridDim.x); fetch(0); }
-        __syncthreads();                                  // stage st^1 complete; stage st free for chunk c+2
+    };
+
+    // chunk c lives in register set c & 1 and in LDS stage c & 1
+    __syncthreads();                                    // (a previous item's last multiplies are done with stage 0)
+    commit(S0, 0);
+    if (nchunks > 2) fetch(S0, 2);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+      multiply(0);
+      if (c + 1 < nchunks) {                            // chunk c+1 -> stage 1 while slower waves still multiply chunk c
+        commit(S1, 1);
+        if (c + 3 < nchunks) fetch(S1, c + 3);
+        __syncthreads();
+        multiply(1);
+        if (c + 2 < nchunks) {
+          commit(S0, 0);
+          if (c + 4 < nchunks) fetch(S0, c + 4);
+          __syncthreads();
+        }
       }
     }
 
