@@ -136,16 +136,47 @@ class _GradMode:
     """When `inplace` is set (by TrainStep around backward) the weight-gradient kernels ADD straight into
     the parameters' preallocated `.grad` (FlatParams views) and backward returns None for them: this skips
     ~180 tiny autograd accumulate-adds and as many allocations per step.  Off by default, so
-    torch.autograd.grad / plain .backward() keep their usual semantics."""
+    torch.autograd.grad / plain .backward() keep their usual semantics.
+
+    `side` (a HIP stream, set by `inplace_param_grads(side_stream=...)`): the weight-gradient kernels of the
+    convolutions are not on the critical path of backward (nothing downstream consumes dW), so they are launched on
+    that stream -- forked after dY exists, joined by the caller before the optimizer -- and fill the CUs that the
+    dependent chain of small dgrad / norm kernels leaves idle.  Legal under stream capture (fork / join by events)."""
     inplace = False
+    side = None
+    pending = []          # (x, dy, dw, db, workspace, shape): weight gradients not launched yet
+    launched = []         # the same tuples after launch, held until the join (their buffers are in use on the side stream)
+    batch = 8             # fork the side stream once per this many layers (few cross-stream edges in a captured graph)
+
+
+def flush_wgrads():
+    """Launch the queued weight-gradient kernels on the side stream (one fork for the whole batch)."""
+    side, q = _GradMode.side, _GradMode.pending
+    if not q:
+        return
+    L = lib()
+    side.wait_stream(torch.cuda.current_stream())                             # fork: every queued dY (and the zeroed .grad) exists
+    with torch.cuda.stream(side):
+        for (x, dy, dw, db, ws, (B, Cin, Cout, H, W, ks)) in q:
+            L.afd_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), B, Cin, Cout, H, W, ks, 1, _p(ws), side.cuda_stream)
+    _GradMode.launched.extend(q)
+    _GradMode.pending = []
 
 
 class inplace_param_grads:
+    def __init__(self, side_stream=None, batch=8):
+        self.side_stream, self.batch = side_stream, batch
+
     def __enter__(self):
-        self.prev, _GradMode.inplace = _GradMode.inplace, True
+        self.prev, self.prev_side = _GradMode.inplace, _GradMode.side
+        _GradMode.inplace, _GradMode.side, _GradMode.batch = True, self.side_stream, self.batch
 
     def __exit__(self, *a):
-        _GradMode.inplace = self.prev
+        if self.side_stream is not None:
+            flush_wgrads()
+            torch.cuda.current_stream().wait_stream(self.side_stream)        # join: every dW is in .grad
+            _GradMode.launched = []                                          # buffers may be freed now (main-stream order)
+        _GradMode.inplace, _GradMode.side = self.prev, self.prev_side
 
 
 def _direct(*params):
@@ -345,8 +376,16 @@ class Conv(torch.autograd.Function):
             ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
             wp, bp = ctx.w_param, ctx.b_param
             if _direct(wp, bp) and wp.grad.numel() == w.numel():
-                L.afd_conv_wgrad(_p(x), _p(dy), _p(wp.grad), _p(bp.grad) if bp is not None else None,
-                                 B, Cin, Cout, H, W, ks, 1, _p(ws), _stream())
+                side = _GradMode.side
+                if side is None:
+                    L.afd_conv_wgrad(_p(x), _p(dy), _p(wp.grad), _p(bp.grad) if bp is not None else None,
+                                     B, Cin, Cout, H, W, ks, 1, _p(ws), _stream())
+                else:
+                    # queued with references to x / dY / workspace: while we hold them autograd cannot add into dY in
+                    # place (it only does so when it owns the last reference) and the allocator cannot hand them out
+                    _GradMode.pending.append((x, dy, wp.grad, bp.grad if bp is not None else None, ws, (B, Cin, Cout, H, W, ks)))
+                    if len(_GradMode.pending) >= _GradMode.batch:
+                        flush_wgrads()
             else:
                 dw = torch.empty_like(w)
                 db = torch.empty(Cout, device=x.device, dtype=torch.float32) if ctx.has_bias else None

@@ -139,8 +139,16 @@ class TrainStep:
     (one 23.6 MB exchange) and AdamW then run after the replay.  The CPU-generator timestep draw and the
     H2D copies always stay outside the graph."""
 
-    def __init__(self, model, diffusion, lr, graph=False, distributed=None, n_buckets=4):
+    def __init__(self, model, diffusion, lr, graph=False, distributed=None, n_buckets=4, overlap_wgrad=None):
         self.model, self.diffusion = model, diffusion
+        # weight-gradient kernels on a second stream (ops._GradMode.side): off the critical path of backward, they fill
+        # the CUs the dependent chain of small kernels leaves idle.  Measured on MI355X (B=256): eager 12.0 -> 11.1
+        # ms/step, captured graph 11.45 -> 11.3 (forks batched 16 layers at a time: every fork is a cross-stream edge
+        # in the graph, and 57 of them cost more than the overlap returns)
+        if overlap_wgrad is None:
+            overlap_wgrad = True
+        self.wgrad_stream = torch.cuda.Stream() if overlap_wgrad else None
+        self.wgrad_batch = 16 if graph else 8
         self.opt = FusedAdamW(model, lr=lr)
         want_ddp = distributed if distributed is not None else dist.is_initialized()
         self.ddp = GradAllReduce(self.opt.fp.grad, n_buckets) if want_ddp else None
@@ -153,7 +161,7 @@ class TrainStep:
         pred = self.model(x_t, t)
         loss = ops.mse_loss(noise, pred)
         self.opt.zero_grad()
-        with ops.inplace_param_grads():          # weight-gradient kernels add straight into the flat .grad views
+        with ops.inplace_param_grads(self.wgrad_stream, self.wgrad_batch):   # weight gradients add straight into the flat .grad views
             loss.backward()
         return loss.detach()
 

@@ -204,7 +204,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--variant", type=int, default=3)
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches only")
+    ap.add_argument("--graph", action="store_true", help="hipGraph replay only (default: probe both after warm-up, keep the faster)")
     ap.add_argument("--no-sample", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
@@ -231,8 +232,6 @@ def main():
         model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET) if args.variant else None,
                           device=dev, variant=args.variant).to(dev)
     diff = afdm.Diffusion(noise_steps=1000, img_size=32, device=dev)
-    use_graph = not args.no_graph
-    step = afdm.TrainStep(model, diff, lr=3e-4, graph=use_graph, distributed=(world > 1))
     g = torch.Generator().manual_seed(42 + rank)
     images = (torch.rand(args.batch, 3, 32, 32, generator=g) * 2 - 1).to(dev)
     torch.manual_seed(42 + rank)
@@ -243,19 +242,49 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    graph_ok = use_graph
-    log(f"rank {rank}/{world}: model ready, warm-up ({'hipGraph' if use_graph else 'eager'})")
-    try:
-        for _ in range(args.warmup):
-            loss = step(images)
-    except Exception as e:                        # capture failure: report it and fall back to eager launches
-        if not use_graph:
-            raise
-        print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
-        graph_ok = False
-        step = afdm.TrainStep(model, diff, lr=3e-4, graph=False, distributed=(world > 1))
-        for _ in range(args.warmup):
-            loss = step(images)
+    def make_step(use_graph):
+        """(step callable, graph really in use): a failed capture is reported and falls back to eager launches."""
+        st = afdm.TrainStep(model, diff, lr=3e-4, graph=use_graph, distributed=(world > 1))
+        try:
+            for _ in range(args.warmup):
+                st(images)
+            return st, use_graph
+        except Exception as e:
+            if not use_graph:
+                raise
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            st = afdm.TrainStep(model, diff, lr=3e-4, graph=False, distributed=(world > 1))
+            for _ in range(args.warmup):
+                st(images)
+            return st, False
+
+    def probe(st, n=6):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            st(images)
+        sync()
+        dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)        # every rank takes the same decision
+        return dt.item() / n
+
+    # launch mode: the same step either replayed from a captured hipGraph or launched eagerly (with the weight-gradient
+    # kernels overlapped on a second stream in both).  Which is faster depends on how quickly the host issues ~1000
+    # launches per step, so by default both are probed after warm-up (untimed) and the faster one is measured.
+    if args.no_graph or args.graph:
+        step, graph_ok = make_step(args.graph)
+        log(f"rank {rank}/{world}: model ready ({'hipGraph' if graph_ok else 'eager'})")
+    else:
+        step, graph_ok = make_step(False)
+        t_eager = probe(step)
+        del step
+        step, graph_ok = make_step(True)
+        t_graph = probe(step) if graph_ok else float("inf")
+        log(f"rank {rank}/{world}: probe eager {t_eager * 1e3:.2f} ms/step, hipGraph {t_graph * 1e3:.2f} ms/step")
+        if t_eager < t_graph:
+            del step
+            step, graph_ok = make_step(False)
     sync()
     log("timing train steps")
     t0 = time.perf_counter()
