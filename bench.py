@@ -341,8 +341,11 @@ def main():
                                       "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": traffic,
                                       "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3),
                                       "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
-                                      "basis": "algorithmic direct-form flops (2*9*Cin*Cout per output pixel, SURVEY 8d) / HIP-event time; "
-                                               "the Winograd kernels issue 16/36 of those multiplies on the fp32 MFMA, so frac is not bounded by 1",
+                                      "basis": ("algorithmic direct-form flops (2*9*Cin*Cout per output pixel, SURVEY 8d) / HIP-event time; "
+                                                "the Winograd kernels issue 16/36 of those multiplies on the fp32 MFMA, so frac is not bounded by 1")
+                                               if name.startswith("conv") else
+                                               ("algorithmic attention flops (4*L*L*C forward, 2.5x that backward, SURVEY 8d) / HIP-event time; "
+                                                "fp32 at head dim 8: VALU kernels, priced against the fp32 matrix peak"),
                                       "traffic_source": tsrc}
             else:
                 ach = r["bytes"] / sec / 1e9
