@@ -43,12 +43,12 @@ class SelfAttention(nn.Module):
         C = self.channels
         x = x.reshape(-1, C, self.size, self.size)
         as1x1 = lambda w: w.reshape(w.shape[0], w.shape[1], 1, 1)
-        h = ops.LayerNormC.apply(x, self.ln.weight, self.ln.bias)
+        h, x_res = ops.LayerNormC.apply(x, self.ln.weight, self.ln.bias)         # x_res: x for the residual, via the LN node
         lin = lambda z, w, b, res=None: ops.conv(z, as1x1(w), b, res=res, w_param=w, b_param=b)
         qkv = lin(h, self.mha.in_proj_weight, self.mha.in_proj_bias)
         att = ops.Attention.apply(qkv, self.heads)
-        a = lin(att, self.mha.out_proj.weight, self.mha.out_proj.bias, x)
-        f = ops.LayerNormC.apply(a, self.ff_self[0].weight, self.ff_self[0].bias)
+        a = lin(att, self.mha.out_proj.weight, self.mha.out_proj.bias, x_res)
+        f, a = ops.LayerNormC.apply(a, self.ff_self[0].weight, self.ff_self[0].bias)                 # (a again, via the LN node)
         if torch.is_grad_enabled():
             f = ops.Gelu.apply(lin(f, self.ff_self[1].weight, self.ff_self[1].bias))
         else:

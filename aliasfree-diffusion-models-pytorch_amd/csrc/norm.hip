@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void ln_c_bwd_dx(const float* __restrict__ x, 
                                                    const float* __restrict__ stats, int C, int HW, long pixels,
                                                    const float* __restrict__ gamma, float* __restrict__ dx,
                                                    const float* __restrict__ part, int B, float* __restrict__ dgamma,
-                                                   float* __restrict__ dbeta, int accumulate) {
+                                                   float* __restrict__ dbeta, int accumulate, const float* __restrict__ addp) {
   __shared__ float red[16];
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < pixels) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void ln_c_bwd_dx(const float* __restrict__ x, 
     const float m1 = s1 / (float)C, m2 = s2 / (float)C;
     for (int c = 0; c < C; ++c) {
       const float xh = (x[off + (long)c * HW] - mean) * rstd;
-      dx[off + (long)c * HW] = rstd * (gamma[c] * dy[off + (long)c * HW] - m1 - xh * m2);
+      dx[off + (long)c * HW] = rstd * (gamma[c] * dy[off + (long)c * HW] - m1 - xh * m2) + (addp ? addp[off + (long)c * HW] : 0.f);
     }
   }
   if (dgamma) fold_param_grads(part, B, C, dgamma, dbeta, accumulate, red, blockIdx.x, gridDim.x);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void ln_c_bwd_dx_reg(const float* __restrict__
                                                        const float* __restrict__ stats, int HW, long pixels,
                                                        const float* __restrict__ gamma, float* __restrict__ dx,
                                                        const float* __restrict__ part, int B, float* __restrict__ dgamma,
-                                                       float* __restrict__ dbeta, int accumulate) {
+                                                       float* __restrict__ dbeta, int accumulate, const float* __restrict__ addp) {
   __shared__ float red[16];
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < pixels) {
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void ln_c_bwd_dx_reg(const float* __restrict__
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const float xh = (x[off + (long)c * HW] - mean) * rstd;
-      dx[off + (long)c * HW] = rstd * (g[c] - m1 - xh * m2);
+      dx[off + (long)c * HW] = rstd * (g[c] - m1 - xh * m2) + (addp ? addp[off + (long)c * HW] : 0.f);
     }
   }
   if (dgamma) fold_param_grads(part, B, C, dgamma, dbeta, accumulate, red, blockIdx.x, gridDim.x);
@@ -379,7 +379,7 @@ int afd_layernorm_c_fwd(const float* x, float* y, float* stats_out, int B, int C
 }
 
 int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
-                        const float* gamma, float* dx, float* part, float* dgamma, float* dbeta, int accumulate,
+                        const float* gamma, float* dx, const float* add, float* part, float* dgamma, float* dbeta, int accumulate,
                         afd_stream_t st) {
   AFD_REQUIRE(x && dy && stats && gamma && dx && part && B > 0 && C > 0 && HW > 0, "afd_layernorm_c_bwd: bad argument");
   AFD_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "afd_layernorm_c_bwd: dgamma and dbeta come together");
@@ -389,10 +389,10 @@ int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int
   // plane partials first: the dx kernel's tail folds them into dgamma / dbeta
   hipLaunchKernelGGL(ln_c_bwd_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, x, dy, stats, C, HW, planes, part);
   switch (C) {
-    case 32:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<32>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate); break;
-    case 64:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<64>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate); break;
-    case 128: hipLaunchKernelGGL(ln_c_bwd_dx_reg<128>, grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate); break;
-    default:  hipLaunchKernelGGL(ln_c_bwd_dx, grid, dim3(256), 0, s, x, dy, stats, C, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate);
+    case 32:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<32>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate, add); break;
+    case 64:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<64>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate, add); break;
+    case 128: hipLaunchKernelGGL(ln_c_bwd_dx_reg<128>, grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate, add); break;
+    default:  hipLaunchKernelGGL(ln_c_bwd_dx, grid, dim3(256), 0, s, x, dy, stats, C, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate, add);
   }
   return check_launch("afd_layernorm_c_bwd");
 }

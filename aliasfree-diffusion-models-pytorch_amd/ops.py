@@ -417,7 +417,11 @@ def conv_infer(x, w, bias=None, res=None, act=0):
 # F10 attention block pieces
 # ---------------------------------------------------------------------------------------------
 class LayerNormC(torch.autograd.Function):
-    """nn.LayerNorm([C]) applied to the (B, L, C) token view of an NCHW tensor, without the transposes."""
+    """nn.LayerNorm([C]) applied to the (B, L, C) token view of an NCHW tensor, without the transposes.
+
+    Returns (y, x_res): x_res is x again, for the residual branch that every LayerNorm of the attention block sits
+    beside (y -> ... -> + x).  Routing the residual through this node means backward receives BOTH gradients of x
+    and the kernel writes LN'(dy) + d(x_res) in one pass, instead of autograd launching a separate add."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta):
@@ -429,19 +433,26 @@ class LayerNormC(torch.autograd.Function):
         lib().afd_layernorm_c_fwd(_p(x), _p(y), _p(stats), B, C, H * W, LN_EPS, _p(gamma), _p(beta), _stream())
         ctx.save_for_backward(x, gamma, stats)
         ctx.beta_param = beta
-        return y
+        return y, x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres):
         x, gamma, stats = ctx.saved_tensors
         B, C, H, W = x.shape
-        dy = _c(dy)
+        if dy is None:                                   # only the residual output was used
+            return dres, None, None
+        dy, dres = _c(dy), _c(dres)
         dx = torch.empty_like(x)
         part = torch.empty(B, 2, C, device=x.device, dtype=torch.float32)
         dg, db, acc, (dgamma, dbeta) = _gn_param_targets(C, gamma, ctx.beta_param, x.device)
-        lib().afd_layernorm_c_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(dx), _p(part), _p(dg), _p(db), acc,
+        lib().afd_layernorm_c_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(dx), _p(dres), _p(part), _p(dg), _p(db), acc,
                                   _stream())
         return dx, dgamma, dbeta
+
+
+def layernorm_c(x, gamma, beta):
+    """y only (no residual routed through the node)."""
+    return LayerNormC.apply(x, gamma, beta)[0]
 
 
 class Attention(torch.autograd.Function):

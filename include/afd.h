@@ -149,7 +149,9 @@ int afd_conv3x3_wino_dgrad(const float* dy, const float* w, float* dx,
 int afd_layernorm_c_fwd(const float* x, float* y, float* stats_out, int B, int C, int HW, float eps,
                         const float* gamma, const float* beta, afd_stream_t stream);
 int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
-                        const float* gamma, float* dx, float* dgamma_dbeta_partial /* (B,2,C) */,
+                        const float* gamma, float* dx, const float* add_to_dx /* or NULL: dx = LN'(dy) + add (the gradient
+                        that reaches x through the block's residual branch: one pass instead of an extra add) */,
+                        float* dgamma_dbeta_partial /* (B,2,C) */,
                         float* dgamma /* (C) or NULL */, float* dbeta /* (C) or NULL */, int accumulate,
                         afd_stream_t stream);
 

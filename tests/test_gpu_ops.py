@@ -313,13 +313,24 @@ def test_layernorm_c(A, shape):
     tok = leaves[0].reshape(B, C, H * W).transpose(1, 2)
     yo = F.layer_norm(tok, (C,), leaves[1], leaves[2]).transpose(1, 2).reshape(shape)
     dy = torch.randn(shape, generator=g)
-    go = torch.autograd.grad(yo, leaves, dy)
+    go = torch.autograd.grad(yo, leaves, dy, retain_graph=True)
     dl = [t.detach().to(dev).requires_grad_(True) for t in leaves]
-    yd = ops.LayerNormC.apply(*dl)
+    yd, xres = ops.LayerNormC.apply(*dl)
     gd = torch.autograd.grad(yd, dl, dy.to(dev))
     assert rel_l2(yd.detach().cpu(), yo.detach()) < TOL
+    assert torch.equal(xres.detach().cpu(), x)
     for a, b in zip(gd, go):
         assert rel_l2(a.cpu(), b) < 3e-5
+    # the residual routed through the node: d/dx [LN(x) . dy + x . dr] in one backward kernel
+    dr = torch.randn(shape, generator=g)
+    yo = F.layer_norm(tok, (C,), leaves[1], leaves[2]).transpose(1, 2).reshape(shape)
+    go2 = torch.autograd.grad((yo * dy).sum() + (leaves[0] * dr).sum(), leaves)
+    yd, xres = ops.LayerNormC.apply(*dl)
+    gd2 = torch.autograd.grad((yd * dy.to(dev)).sum() + (xres * dr.to(dev)).sum(), dl)
+    for a, b in zip(gd2, go2):
+        assert rel_l2(a.cpu(), b) < 3e-5
+    (gres,) = torch.autograd.grad((ops.LayerNormC.apply(*dl)[1] * dr.to(dev)).sum(), dl[:1])     # residual output alone
+    assert rel_l2(gres.cpu(), dr) < 1e-7
 
 
 @pytest.mark.parametrize("cfg", [(2, 4, 8, 1024), (2, 4, 8, 256), (3, 2, 8, 512), (3, 4, 16, 256), (2, 4, 32, 64), (5, 4, 32, 16),
