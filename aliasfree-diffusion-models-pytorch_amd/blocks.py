@@ -67,7 +67,10 @@ class _DoubleConvBase(nn.Module):
 
     def forward(self, x, emb=None):
         conv1, norm1, conv2, norm2 = self._parts()
-        h = ops.conv(x, conv1.weight)
+        if self.residual:                                  # x for the residual comes back through the conv node
+            h, x = ops.conv(x, conv1.weight, fork=True)
+        else:
+            h = ops.conv(x, conv1.weight)
         if self.filtered:
             h = ops.GroupNormFiltAct.apply(h, norm1.weight, norm1.bias, None, self._tu, self._td)
         else:

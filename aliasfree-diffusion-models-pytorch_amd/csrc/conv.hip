@@ -914,10 +914,10 @@ int afd_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, cons
   return check_launch("afd_conv3x3_wino_fwd");
 }
 
-int afd_conv3x3_wino_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H, int W, void* workspace,
-                           int weights_ready, afd_stream_t st) {
+int afd_conv3x3_wino_dgrad(const float* dy, const float* w, float* dx, const float* add_to_dx, int B, int Cin, int Cout, int H, int W,
+                           void* workspace, int weights_ready, afd_stream_t st) {
   AFD_REQUIRE(dy && w && dx && workspace && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "afd_conv3x3_wino_dgrad: bad argument");
-  AFD_REQUIRE(wino_conv(dy, w, nullptr, nullptr, dx, static_cast<float*>(workspace), B, Cout, Cin, H, W, 0, true, weights_ready != 0, as_stream(st)),
+  AFD_REQUIRE(wino_conv(dy, w, nullptr, add_to_dx, dx, static_cast<float*>(workspace), B, Cout, Cin, H, W, 0, true, weights_ready != 0, as_stream(st)),
               "afd_conv3x3_wino_dgrad: shape (%d,%d->%d,%dx%d) is not covered", B, Cin, Cout, H, W);
   return check_launch("afd_conv3x3_wino_dgrad");
 }

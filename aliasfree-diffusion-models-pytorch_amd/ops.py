@@ -335,10 +335,13 @@ def _conv_fwd(x, w, bias, res, y, B, Cin, Cout, H, W, ks, act, want_dgrad=False)
 
 
 class Conv(torch.autograd.Function):
-    """y = conv(x, w) + bias + res.  (The GELU epilogue is only used by `conv_infer`.)"""
+    """y = conv(x, w) + bias + res.  (The GELU epilogue is only used by `conv_infer`.)
+
+    fork=True returns (y, x again): the residual branch of a block that STARTS with this convolution takes x from
+    here, so backward receives both gradients of x and the dgrad kernel's epilogue adds them (no autograd add)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, w_param=None, b_param=None):
+    def forward(ctx, x, w, bias, res, w_param=None, b_param=None, fork=False):
         # w may be a reshaped VIEW of a parameter (Linear weights used as 1x1 kernels); w_param / b_param are
         # the leaf Parameters whose .grad the in-place mode accumulates into
         _chk(x, w, bias, res)
@@ -350,10 +353,10 @@ class Conv(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias, ctx.has_res = bias is not None, res is not None
         ctx.w_param, ctx.b_param = w_param, b_param
-        return y
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dfork=None):
         x, w = ctx.saved_tensors
         B, Cin, H, W = x.shape
         Cout, ks = w.shape[0], w.shape[-1]
@@ -362,15 +365,18 @@ class Conv(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            dfork = _c(dfork)
             nb = L.afd_conv3x3_wino_workspace_bytes(B, Cin, Cout, H, W, 1) if ks == 3 else 0
             if nb:
                 if ctx.u_dgrad is not None:            # produced together with the forward image
                     u, ready = ctx.u_dgrad, 1
                 else:
                     u, ready = _WinoWeights.get(w, nb, 1)
-                L.afd_conv3x3_wino_dgrad(_p(dy), _p(w), _p(dx), B, Cin, Cout, H, W, _p(u), ready, _stream())
+                L.afd_conv3x3_wino_dgrad(_p(dy), _p(w), _p(dx), _p(dfork), B, Cin, Cout, H, W, _p(u), ready, _stream())
             else:
                 L.afd_conv_dgrad(_p(dy), _p(w), _p(dx), B, Cin, Cout, H, W, ks, _stream())
+                if dfork is not None:
+                    dx = dx + dfork
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             nbytes = L.afd_conv_wgrad_workspace_bytes(B, Cin, Cout, H, W, ks)
             ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
@@ -390,16 +396,17 @@ class Conv(torch.autograd.Function):
                 dw = torch.empty_like(w)
                 db = torch.empty(Cout, device=x.device, dtype=torch.float32) if ctx.has_bias else None
                 L.afd_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), B, Cin, Cout, H, W, ks, 0, _p(ws), _stream())
-        return dx, dw, db, (dy if ctx.has_res else None), None, None
+        return dx, dw, db, (dy if ctx.has_res else None), None, None, None
 
 
-def conv(x, w, bias=None, res=None, w_param=None, b_param=None):
-    """w_param / b_param: the leaf Parameters behind `w` / `bias` (enables in-place grad accumulation)."""
+def conv(x, w, bias=None, res=None, w_param=None, b_param=None, fork=False):
+    """w_param / b_param: the leaf Parameters behind `w` / `bias` (enables in-place grad accumulation).
+    fork: also return x (for the residual of the block this convolution opens), see Conv."""
     if w_param is None and isinstance(w, torch.nn.Parameter):
         w_param = w
     if b_param is None and isinstance(bias, torch.nn.Parameter):
         b_param = bias
-    return Conv.apply(x, w, bias, res, w_param, b_param)
+    return Conv.apply(x, w, bias, res, w_param, b_param, fork)
 
 
 def conv_infer(x, w, bias=None, res=None, act=0):

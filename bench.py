@@ -146,7 +146,7 @@ def conv_layer_times(L, s, dev, B, ci, co, S, reps=5):
     if ci <= 3:
         td = 0.0
     elif nd:
-        td = ev_time(lambda: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), B, ci, co, S, S, u.data_ptr(), 0, s), reps)
+        td = ev_time(lambda: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 0, s), reps)
     else:
         td = ev_time(lambda: L.afd_conv_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), B, ci, co, S, S, 3, s), reps)
     tw = ev_time(lambda: L.afd_conv_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, B, ci, co, S, S, 3, 0, ws.data_ptr(), s), reps)

@@ -141,7 +141,8 @@ int afd_conv3x3_wino_weights(const float* w, float* u_fwd, float* u_dgrad, int C
 int afd_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
                          int B, int Cin, int Cout, int H, int W, int act, void* workspace, int weights_ready,
                          afd_stream_t stream);
-int afd_conv3x3_wino_dgrad(const float* dy, const float* w, float* dx,
+int afd_conv3x3_wino_dgrad(const float* dy, const float* w, float* dx, const float* add_to_dx /* or NULL: dx = dgrad + add,
+                           the gradient that reaches x through the block's residual branch */,
                            int B, int Cin, int Cout, int H, int W, void* workspace, int weights_ready, afd_stream_t stream);
 
 /* ---- F10: LayerNorm over channels of an NCHW tensor (= nn.LayerNorm([C]) on (B,L,C) tokens) ------

@@ -244,6 +244,13 @@ def _conv_case(ops, dev, case):
     assert rel_l2(yd.detach().cpu(), yo.detach()) < TOL
     for name, a, b in zip(("dx", "dw", "db/dres", "dres"), gd, go):
         assert rel_l2(a.cpu(), b) < TOL, name
+    if ks == 3 and not has_bias and not has_res:
+        # the residual fork: (y, x again) -- backward adds the residual's gradient inside the dgrad kernel
+        dr = torch.randn(x.shape, generator=g)
+        yf, xr = ops.conv(dl[0], dl[1], fork=True)
+        assert torch.equal(xr.detach(), dl[0].detach())
+        (gx,) = torch.autograd.grad((yf * dy.to(dev)).sum() + (xr * dr.to(dev)).sum(), dl[:1])
+        assert rel_l2(gx.cpu(), go[0] + dr.double()) < TOL
     # no-grad path with the fused GELU epilogue
     with torch.no_grad():
         yi = ops.conv_infer(dl[0], dl[1], dl[2] if has_bias else None, dl[-1] if has_res else None, act=1)
