@@ -734,7 +734,6 @@ int wino_plan(int B, int K, int N, int H, int W);
 bool wino_conv(const float* x, const float* w, const float* bias, const float* res, float* y, float* U, int B, int K, int N, int H,
                int W, int act, bool dgrad, bool weights_ready, hipStream_t s);
 void wino_set_mode(int m);
-void wino_set_dbg(int d);
 void wino_weights_launch(const float* w, float* Uf, float* Ud, int Cin, int Cout, hipStream_t s);
 void wino_set_grid(int g);
 int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, int* cps, int* nchunks);
@@ -848,7 +847,6 @@ extern "C" {
 int afd_debug_conv_path(int mode) {
   if (mode >= 8 && mode <= 10) { pw_set_mode(mode - 8); return AFD_OK; }     // 1x1 streaming kernel: 8 = by rule (default), 9 = off, 10 = forced
   if (mode >= 100000 && mode < 200000) { wino_set_grid(mode - 100000); return AFD_OK; }   // Winograd persistent grid size (0 = default)
-  if (mode >= 1000 && mode < 1064) { wino_set_dbg(mode - 1000); return AFD_OK; }   // ablation switches (tools/wino_abl.py)
   if (mode >= 96 && mode <= 98) { wgrad_wino_set_mode(mode - 96); return AFD_OK; }   // Winograd wgrad: 96 = by rule (default), 97 = off, 98 = whenever covered
   if (mode >= 64 && mode <= 70) { wino_set_mode(mode - 64); return AFD_OK; }   // Winograd 3x3: 64 = by rule (default), 65 = off, 66..69 = forced, workgroups of 64x64 / 32x64 / 64x32 / 32x32 (channels x tiles)
   if (mode >= 32 && mode <= 34) { g_wgrad_nw = mode == 32 ? 4 : (mode == 33 ? 8 : 0); return AFD_OK; }   // wgrad waves: 4 / 8 / auto

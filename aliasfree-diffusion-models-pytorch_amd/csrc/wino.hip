@@ -490,8 +490,6 @@ static void wino_sk_launch(const float* x, const float* U, const float* bias, co
 
 static int g_wino_grid = 0;      // test / tuning hook: persistent grid size (0 = fill the chip once)
 void wino_set_grid(int g) { g_wino_grid = g; }
-static int g_wino_dbg = 0;
-void wino_set_dbg(int d) { g_wino_dbg = d; }
 static int g_wino_mode = 0;        // 0 = by rule, 1 = off, 2..5 = whenever the shape is supported: workgroups of 64x64, 32x64, 64x32, 32x32 (channels x tiles); 6 = the small-map split-K kernel wherever covered
 void wino_set_mode(int m) { g_wino_mode = m; }
 
@@ -554,7 +552,7 @@ bool wino_conv(const float* x, const float* w, const float* bias, const float* r
     if (W == 4) wino_sk_launch<4>(x, U, bias, res, y, B, K, N, act, s); else wino_sk_launch<8>(x, U, bias, res, y, B, K, N, act, s);
     return true;
   }
-  if (!weights_ready && !(g_wino_dbg & 32))
+  if (!weights_ready)
     hipLaunchKernelGGL(wino_weights, dim3((unsigned)((K * N / 64 + 3) / 4)), dim3(256), 0, s, w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout);
 #define AFD_WINO(GEO_)                                                                            \
   if (bn == 64 && nt == 64) wino_launch_t<GEO_, 64, 64>(x, U, bias, res, y, B, K, N, act, s);     \
