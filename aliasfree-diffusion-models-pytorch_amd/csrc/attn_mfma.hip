@@ -15,6 +15,7 @@ namespace afd {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kD = 8, kTK = 64;                      // head dim, rows of the streamed operand per LDS tile
+constexpr int kNE = kD * kTK / 256;                  // staged values per thread and operand
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, kWave); }     // value of lane ^ 32
@@ -68,14 +69,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma8(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) oa[j][i] = (f2){0.f, 0.f};
 
+  // the next K / V tile travels global -> registers while the current one is multiplied (2 x 2 values per thread)
+  float kreg[kNE], vreg[kNE];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < kNE; ++e) {
+      const int i = threadIdx.x + 256 * e, j = i / kTK, rr = i % kTK;
+      kreg[e] = kp[(long)j * L + k0 + rr];
+      vreg[e] = vp[(long)j * L + k0 + rr];
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < L; k0 += kTK) {
     __syncthreads();
-    for (int i = threadIdx.x; i < kD * kTK; i += 256) {
-      const int j = i / kTK, rr = i % kTK;
-      Kd[j * kTK + rr] = kp[(long)j * L + k0 + rr];
-      Vr[rr * kD + j] = vp[(long)j * L + k0 + rr];
+#pragma unroll
+    for (int e = 0; e < kNE; ++e) {
+      const int i = threadIdx.x + 256 * e, j = i / kTK, rr = i % kTK;
+      Kd[j * kTK + rr] = kreg[e];
+      Vr[rr * kD + j] = vreg[e];
     }
     __syncthreads();
+    if (k0 + kTK < L) fetch(k0 + kTK);
 #pragma unroll
     for (int kt = 0; kt < kTK / 32; ++kt) {
       float ak[4];
@@ -163,11 +177,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma8(const float* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[j][i] = (f2){0.f, 0.f};
   }
+  float kreg[kNE], vreg[kNE];                           // next K / V tile in flight during the multiplies
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < kNE; ++e) {
+      const int i = threadIdx.x + 256 * e, j = i / kTK, rr = i % kTK;
+      kreg[e] = kp[(long)j * L + k0 + rr];
+      vreg[e] = vp[(long)j * L + k0 + rr];
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < L; k0 += kTK) {
     __syncthreads();
-    stage_both(kp, L, k0, Kd, Kr, 1.f);
-    stage_both(vp, L, k0, Vd, nullptr, 1.f);
+#pragma unroll
+    for (int e = 0; e < kNE; ++e) {
+      const int i = threadIdx.x + 256 * e, j = i / kTK, rr = i % kTK;
+      Kd[j * kTK + rr] = kreg[e]; Kr[rr * kD + j] = kreg[e];
+      Vd[j * kTK + rr] = vreg[e];
+    }
     __syncthreads();
+    if (k0 + kTK < L) fetch(k0 + kTK);
 #pragma unroll
     for (int kt = 0; kt < kTK / 32; ++kt) {
       float ak[4], av[4];
@@ -245,12 +274,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma8(const float* __rest
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dk[j][i] = (f2){0.f, 0.f}; dv[j][i] = (f2){0.f, 0.f}; }
   }
+  float qreg[kNE], greg[kNE], lreg = 0.f, dreg = 0.f;       // next Q / dO / lse / delta tile in flight during the multiplies
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int e = 0; e < kNE; ++e) {
+      const int i = threadIdx.x + 256 * e, j = i / kTK, rr = i % kTK;
+      qreg[e] = qp[(long)j * L + t0 + rr];
+      greg[e] = gp[(long)j * L + t0 + rr];
+    }
+    if (threadIdx.x < kTK) { lreg = lp[t0 + threadIdx.x] * kLog2e; dreg = dlp[t0 + threadIdx.x]; }
+  };
+  fetch(0);
   for (int t0 = 0; t0 < L; t0 += kTK) {
     __syncthreads();
-    stage_both(qp, L, t0, Qd, Qr, 1.f);
-    stage_both(gp, L, t0, Gd, Gr, 1.f);
-    if (threadIdx.x < kTK) { Ls[threadIdx.x] = lp[t0 + threadIdx.x] * kLog2e; Ds[threadIdx.x] = dlp[t0 + threadIdx.x]; }
+#pragma unroll
+    for (int e = 0; e < kNE; ++e) {
+      const int i = threadIdx.x + 256 * e, j = i / kTK, rr = i % kTK;
+      Qd[j * kTK + rr] = qreg[e]; Qr[rr * kD + j] = qreg[e];
+      Gd[j * kTK + rr] = greg[e]; Gr[rr * kD + j] = greg[e];
+    }
+    if (threadIdx.x < kTK) { Ls[threadIdx.x] = lreg; Ds[threadIdx.x] = dreg; }
     __syncthreads();
+    if (t0 + kTK < L) fetch(t0 + kTK);
 #pragma unroll
     for (int qt = 0; qt < kTK / 32; ++qt) {
       float aq[4], ag[4];

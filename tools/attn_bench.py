@@ -15,7 +15,8 @@ for (C, S) in [(32, 32), (32, 16), (64, 16), (128, 8)]:
         print(f"C={C} L={Lq} d={C//4} R={r}: fwd {tf*1e3:8.1f} us  bwd {tb*1e3:8.1f} us")
     L_.afd_debug_attn_rows(0)
     if C == 32:
-        for f in (8, 9):
+        for f in (10, 11):
             L_.afd_debug_attn_rows(f)
             tb = bench.ev_time(lambda: L_.afd_attn_bwd(qkv.data_ptr(), o.data_ptr(), o.data_ptr(), lse.data_ptr(), dq.data_ptr(), dl.data_ptr(), B, 4, C // 4, Lq, s), reps=5, warm=1)
-            print(f"C={C} L={Lq} d={C//4} fused={'on' if f == 9 else 'off'}: bwd {tb*1e3:8.1f} us")
+            print(f"C={C} L={Lq} d={C//4} mfma8 bwd at every L={'on' if f == 11 else 'off'}: bwd {tb*1e3:8.1f} us")
+        L_.afd_debug_attn_rows(10)
