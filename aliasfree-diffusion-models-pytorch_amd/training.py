@@ -148,7 +148,7 @@ class TrainStep:
         if overlap_wgrad is None:
             overlap_wgrad = True
         self.wgrad_stream = torch.cuda.Stream() if overlap_wgrad else None
-        self.wgrad_batch = 16 if graph else 8
+        self.wgrad_batch = 16 if graph else 4
         self.opt = FusedAdamW(model, lr=lr)
         want_ddp = distributed if distributed is not None else dist.is_initialized()
         self.ddp = GradAllReduce(self.opt.fp.grad, n_buckets) if want_ddp else None
