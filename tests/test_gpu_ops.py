@@ -271,6 +271,50 @@ def test_conv_full_size_matches_double_precision_sample(A):
         assert rel_l2(y[b:b + 1], ref) < 5e-6
 
 
+@pytest.mark.parametrize("shape", [(64, 64, 32), (128, 128, 16), (256, 256, 8), (256, 128, 8), (128, 128, 4), (256, 256, 4)],
+                         ids=lambda t: f"{t[0]}to{t[1]}_{t[2]}x{t[2]}")
+def test_conv_full_batch_winograd_vs_direct_and_fp64(A, shape):
+    """BASELINE batch (256), the layer shapes of the Config-D decoder / bottleneck: the kernels the dispatch rule picks
+    (Winograd main kernel, small-map split-K kernel, Winograd wgrad) against the direct implicit-GEMM kernels on the
+    whole batch (two independent fp32 algorithms agreeing to ~1e-6), plus an fp64 spot check of forward, dgrad and
+    wgrad contributions on two images."""
+    afdm, ops, dev = A
+    ci, co, S = shape
+    g = _g(ci + co + S)
+    x = torch.randn(256, ci, S, S, generator=g).to(dev)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)).to(dev)
+    dy = torch.randn(256, co, S, S, generator=g).to(dev)
+    L = afdm.lib()
+    out = {}
+    try:
+        for name, modes in (("rule", (64, 96)), ("direct", (65, 97))):
+            for m in modes:
+                L.afd_debug_conv_path(m)
+            xd, wd = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            y = ops.conv(xd, wd)
+            gx, gw = torch.autograd.grad(y, (xd, wd), dy)
+            out[name] = (y.detach(), gx, gw)
+    finally:
+        L.afd_debug_conv_path(64)
+        L.afd_debug_conv_path(96)
+    assert L.afd_conv3x3_wino_workspace_bytes(256, ci, co, S, S, 0) > 0          # the rule really took a Winograd kernel
+    for a, b, what in zip(out["rule"], out["direct"], ("y", "dx", "dw")):
+        assert rel_l2(a.cpu(), b.cpu()) < 3e-6, what
+    for i in (3, 254):
+        xi = x[i:i + 1].cpu().double().requires_grad_(True)
+        yi = F.conv2d(xi, w.cpu().double(), padding=1)
+        (dxi,) = torch.autograd.grad(yi, xi, dy[i:i + 1].cpu().double())
+        assert rel_l2(out["rule"][0][i:i + 1].cpu(), yi.detach()) < 5e-6
+        assert rel_l2(out["rule"][1][i:i + 1].cpu(), dxi) < 5e-6
+    # wgrad is linear in the batch: the sum over a 16-image slice, in fp64, against the same slice on the device
+    sl = slice(100, 116)
+    ws = w.cpu().double().requires_grad_(True)
+    (dws,) = torch.autograd.grad(F.conv2d(x[sl].cpu().double(), ws, padding=1), ws, dy[sl].cpu().double())
+    wd = w.clone().requires_grad_(True)
+    (dwd,) = torch.autograd.grad(ops.conv(x[sl].contiguous(), wd), wd, dy[sl].contiguous())
+    assert rel_l2(dwd.cpu(), dws) < 1e-5
+
+
 def test_pointwise_full_batch_matches_double_precision(A):
     """BASELINE batch for sa6's in_proj (32->96 @32x32, B=256: the streaming kernel by the default rule) fwd + dgrad,
     spot-checked on 4 images against fp64."""
