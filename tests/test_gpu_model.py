@@ -194,6 +194,26 @@ def test_train_step_vs_reference(A, conv_path):
     assert np.allclose(cs[:, 1], g["param_checksums_after2"][:, 1], rtol=1e-3, atol=0.1)   # |.|-sums incl. zero-init biases after 2 Adam steps
 
 
+def test_overlapped_weight_gradients_are_bitwise_equal(A):
+    """The weight-gradient kernels on the second stream (TrainStep(overlap_wgrad=True)) change WHEN they run, not what
+    they compute: after two steps every parameter is bit-identical to the single-stream run, and a repeat of the same
+    run is bit-identical to itself (no atomics anywhere)."""
+    afdm, dev = A
+    g = load_golden("train_step.npz")
+    images, t0, e0 = T(g["images"]).to(dev), T(g["t0"]), T(g["eps0"]).to(dev)
+    t1, e1 = T(g["t1"]), T(g["eps1"]).to(dev)
+    outs = []
+    for overlap in (False, True, True):
+        model, diff = _train_setup(afdm, dev)
+        step = afdm.TrainStep(model, diff, lr=3e-4, graph=False, overlap_wgrad=overlap)
+        step(images, t=t0, eps=e0)
+        step(images, t=t1, eps=e1)
+        torch.cuda.synchronize()
+        outs.append(torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[1], outs[2])
+
+
 def test_graph_replay_equals_eager(A):
     afdm, dev = A
     g = load_golden("train_step.npz")
