@@ -171,8 +171,10 @@ class inplace_param_grads:
         self.prev, self.prev_side = _GradMode.inplace, _GradMode.side
         _GradMode.inplace, _GradMode.side, _GradMode.batch = True, self.side_stream, self.batch
 
-    def __exit__(self, *a):
+    def __exit__(self, exc_type, *a):
         if self.side_stream is not None:
+            if exc_type is not None:
+                _GradMode.pending = []                                       # backward failed: drop what was queued
             flush_wgrads()
             torch.cuda.current_stream().wait_stream(self.side_stream)        # join: every dW is in .grad
             _GradMode.launched = []                                          # buffers may be freed now (main-stream order)
