@@ -735,6 +735,7 @@ bool wino_conv(const float* x, const float* w, const float* bias, const float* r
                int W, int act, bool dgrad, bool weights_ready, hipStream_t s);
 void wino_set_mode(int m);
 void wino_weights_launch(const float* w, float* Uf, float* Ud, int Cin, int Cout, hipStream_t s);
+void wino_weights_batched_launch(const afd_wino_desc* descs, const int* wg_desc, int n_wg, hipStream_t s);
 void wino_set_grid(int g);
 int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, int* cps, int* nchunks);
 int wgrad_wino(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
@@ -901,6 +902,12 @@ int afd_conv3x3_wino_weights(const float* w, float* u_fwd, float* u_dgrad, int C
   AFD_REQUIRE(w && (u_fwd || u_dgrad) && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, "afd_conv3x3_wino_weights: bad argument");
   wino_weights_launch(w, u_fwd, u_dgrad, Cin, Cout, as_stream(st));
   return check_launch("afd_conv3x3_wino_weights");
+}
+
+int afd_conv3x3_wino_weights_batched(const afd_wino_desc* descs, const int* wg_desc, int n_wg, afd_stream_t st) {
+  AFD_REQUIRE(descs && wg_desc && n_wg > 0, "afd_conv3x3_wino_weights_batched: bad argument");
+  wino_weights_batched_launch(descs, wg_desc, n_wg, as_stream(st));
+  return check_launch("afd_conv3x3_wino_weights_batched");
 }
 
 int afd_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,

@@ -51,11 +51,10 @@ __device__ __forceinline__ int kperm8(int k) { return 2 * (k & 3) + (k >> 2); } 
 //   Ud[(co>>3)][xi'][ci][kperm8(co&7)] = (G g' G^T)[xi'], g' = w[co][ci] rotated by 180 deg  (dgrad: reduction over co)
 // G J = P G with P swapping rows 0 and 3 (J the 3x3 flip), so the dgrad form is the forward form with the xi indices
 // permuted: no second transform.
-__global__ __launch_bounds__(256) void wino_weights(const float* __restrict__ w, float* __restrict__ Uf, float* __restrict__ Ud,
-                                                    int Cin, int Cout) {
+__device__ __forceinline__ void wino_weights_block(const float* __restrict__ w, float* __restrict__ Uf, float* __restrict__ Ud,
+                                                   int Cin, int Cout, int blk, int lane) {
   // a wave = one 8 x 8 block (8 output x 8 input channels): in BOTH images the 64 values of a transform index form one
   // contiguous 256-byte run, so every store is coalesced
-  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int nci8 = Cin >> 3;
   if (blk >= nci8 * (Cout >> 3)) return;
   const int ci = (blk % nci8) * 8 + (lane & 7), co = (blk / nci8) * 8 + (lane >> 3);
@@ -98,6 +97,17 @@ __global__ __launch_bounds__(256) void wino_weights(const float* __restrict__ w,
         o[(4 * i + j) * xs] = u[4 * pi + pj];
       }
   }
+}
+
+__global__ __launch_bounds__(256) void wino_weights(const float* __restrict__ w, float* __restrict__ Uf, float* __restrict__ Ud,
+                                                    int Cin, int Cout) {
+  wino_weights_block(w, Uf, Ud, Cin, Cout, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// every layer of a model in ONE launch: workgroup g works on layer wg_desc[g] (afd_wino_desc, include/afd.h)
+__global__ __launch_bounds__(256) void wino_weights_batched(const afd_wino_desc* __restrict__ descs, const int* __restrict__ wg_desc) {
+  const afd_wino_desc d = descs[wg_desc[blockIdx.x]];
+  wino_weights_block(d.w, d.u_fwd, d.u_dgrad, d.Cin, d.Cout, (blockIdx.x - d.first_wg) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 template <int GEO, int BN, int NT>
@@ -811,6 +821,10 @@ int wgrad_wino(const float* x, const float* dy, float* part, int B, int Cin, int
 // both (or either) transformed-weight images of a layer in one launch
 void wino_weights_launch(const float* w, float* Uf, float* Ud, int Cin, int Cout, hipStream_t s) {
   hipLaunchKernelGGL(wino_weights, dim3((unsigned)((Cin * Cout / 64 + 3) / 4)), dim3(256), 0, s, w, Uf, Ud, Cin, Cout);
+}
+
+void wino_weights_batched_launch(const afd_wino_desc* descs, const int* wg_desc, int n_wg, hipStream_t s) {
+  hipLaunchKernelGGL(wino_weights_batched, dim3((unsigned)n_wg), dim3(256), 0, s, descs, wg_desc);
 }
 
 }  // namespace afd

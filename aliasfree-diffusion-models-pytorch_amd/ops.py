@@ -289,9 +289,18 @@ class _WinoWeights:
     must contain its own transform launches, because a replay runs after the weights moved."""
     epoch = 0
     store = {}
+    recording = None          # dict filled with the requests of one step (TrainStep's first step), see WinoStepPlan
+    active_plan = None        # WinoStepPlan whose buffers were filled at the start of the current step
 
     @classmethod
     def get(cls, w, nbytes, dgrad):
+        plan = cls.active_plan
+        if plan is not None:
+            u = plan.lookup(w, nbytes, dgrad)
+            if u is not None:
+                return u, 1
+        if cls.recording is not None:
+            cls.recording.setdefault(id(w), [w, 0, 0])[1 + dgrad] = nbytes
         capturing = torch.cuda.is_current_stream_capturing()
         key = (id(w), dgrad)
         stamp = (w._version, cls.epoch, w.data_ptr(), nbytes)
@@ -308,6 +317,49 @@ class _WinoWeights:
             except TypeError:
                 pass
         return u, 0
+
+
+class WinoStepPlan:
+    """Every transformed-weight image a train step needs, produced by ONE launch at the start of the step
+    (afd_conv3x3_wino_weights_batched) instead of one launch per layer on the critical path.  Built from the requests
+    recorded during a first step ({id(w): [w, forward bytes, dgrad bytes]}); valid while the weights keep their
+    addresses (FlatParams views do)."""
+
+    def __init__(self, requests):
+        import struct
+        reqs = [r for r in requests.values() if r[1] or r[2]]
+        self.ok = bool(reqs)
+        if not self.ok:
+            return
+        dev = reqs[0][0].device
+        self.buf = torch.empty(sum(r[1] + r[2] for r in reqs) // 4, device=dev, dtype=torch.float32)
+        self.map, descs, wg, off = {}, b"", [], 0
+        for i, (w, nf, nd) in enumerate(reqs):
+            Cout, Cin = w.shape[0], w.shape[1]
+            uf = self.buf[off:off + nf // 4] if nf else None
+            off += nf // 4
+            ud = self.buf[off:off + nd // 4] if nd else None
+            off += nd // 4
+            self.map[id(w)] = (weakref.ref(w), w.data_ptr(), uf, ud)
+            n_wg = (Cin * Cout // 64 + 3) // 4
+            descs += struct.pack("<QQQiiii", w.data_ptr(), uf.data_ptr() if nf else 0, ud.data_ptr() if nd else 0, Cin, Cout, len(wg), 0)
+            wg += [i] * n_wg
+        self.n_wg = len(wg)
+        self.descs = torch.frombuffer(bytearray(descs), dtype=torch.uint8).to(dev)
+        self.wg = torch.tensor(wg, dtype=torch.int32).to(dev)
+
+    def valid(self):
+        return self.ok and all(r() is not None and r().data_ptr() == ptr for (r, ptr, _, _) in self.map.values())
+
+    def launch(self):
+        lib().afd_conv3x3_wino_weights_batched(_p(self.descs), _p(self.wg), self.n_wg, _stream())
+
+    def lookup(self, w, nbytes, dgrad):
+        e = self.map.get(id(w))
+        if e is None or e[0]() is not w:
+            return None
+        u = e[3] if dgrad else e[2]
+        return u if (u is not None and u.numel() * 4 == nbytes) else None
 
 
 def bump_param_epoch():

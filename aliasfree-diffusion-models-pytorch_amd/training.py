@@ -155,14 +155,27 @@ class TrainStep:
         self.use_graph = graph
         self._graph = None
         self._static = None
+        self._wino_plan, self._wino_requests = None, None      # ops.WinoStepPlan after the first (recording) step
 
     def _fwd_bwd(self, images, t, eps):
-        x_t, noise = self.diffusion.noise_images(images, t, eps)
-        pred = self.model(x_t, t)
-        loss = ops.mse_loss(noise, pred)
-        self.opt.zero_grad()
-        with ops.inplace_param_grads(self.wgrad_stream, self.wgrad_batch):   # weight gradients add straight into the flat .grad views
-            loss.backward()
+        W = ops._WinoWeights
+        if self._wino_plan is not None and self._wino_plan.valid():
+            self._wino_plan.launch()                   # every transformed-weight image of the step, one launch
+            W.active_plan = self._wino_plan
+        elif self._wino_requests is None:
+            self._wino_requests = W.recording = {}     # first step: note which images the dispatch asks for
+        try:
+            x_t, noise = self.diffusion.noise_images(images, t, eps)
+            pred = self.model(x_t, t)
+            loss = ops.mse_loss(noise, pred)
+            self.opt.zero_grad()
+            with ops.inplace_param_grads(self.wgrad_stream, self.wgrad_batch):   # weight gradients add straight into the flat .grad views
+                loss.backward()
+        finally:
+            if W.recording is not None and W.recording is self._wino_requests:
+                W.recording = None
+                self._wino_plan = ops.WinoStepPlan(self._wino_requests)
+            W.active_plan = None
         return loss.detach()
 
     def _update(self):

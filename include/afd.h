@@ -138,6 +138,16 @@ size_t afd_conv3x3_wino_workspace_bytes(int B, int Cin, int Cout, int H, int W, 
  * image with permuted transform indices.  Buffers of 16*Cin*Cout floats each; afterwards call the entry points below
  * with weights_ready = 1. */
 int afd_conv3x3_wino_weights(const float* w, float* u_fwd, float* u_dgrad, int Cin, int Cout, afd_stream_t stream);
+/* ... and of EVERY layer of a model in one launch (a train step transforms ~30 weight tensors; one launch instead of
+ * 30 takes them off the critical path).  descs (DEVICE array): one entry per layer; wg_desc (DEVICE, n_wg ints): the
+ * layer each 256-thread workgroup works on -- layer i owns workgroups [first_wg, first_wg + ceil(Cin*Cout/256)). */
+typedef struct afd_wino_desc {
+  const float* w;        /* (Cout,Cin,3,3) */
+  float* u_fwd;          /* 16*Cin*Cout floats or NULL */
+  float* u_dgrad;        /* 16*Cin*Cout floats or NULL */
+  int Cin, Cout, first_wg, reserved;
+} afd_wino_desc;
+int afd_conv3x3_wino_weights_batched(const afd_wino_desc* descs, const int* wg_desc, int n_wg, afd_stream_t stream);
 int afd_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
                          int B, int Cin, int Cout, int H, int W, int act, void* workspace, int weights_ready,
                          afd_stream_t stream);
