@@ -404,13 +404,14 @@ int afd_layernorm_c_fwd(const float* x, float* y, float* stats_out, int B, int C
 int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
                         const float* gamma, float* dx, const float* add, float* part, float* dgamma, float* dbeta, int accumulate,
                         afd_stream_t st) {
-  AFD_REQUIRE(x && dy && stats && gamma && dx && part && B > 0 && C > 0 && HW > 0, "afd_layernorm_c_bwd: bad argument");
+  AFD_REQUIRE(x && dy && stats && gamma && dx && B > 0 && C > 0 && HW > 0, "afd_layernorm_c_bwd: bad argument");
   AFD_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "afd_layernorm_c_bwd: dgamma and dbeta come together");
+  AFD_REQUIRE(part || !dgamma, "afd_layernorm_c_bwd: the parameter gradients need the partial buffer");
   hipStream_t s = as_stream(st);
   const long pixels = (long)B * HW, planes = (long)B * C;
   const dim3 grid((unsigned)((pixels + 255) / 256));
-  // plane partials first: the dx kernel's tail folds them into dgamma / dbeta
-  hipLaunchKernelGGL(ln_c_bwd_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, x, dy, stats, C, HW, planes, part);
+  // plane partials first: the dx kernel's tail folds them into dgamma / dbeta (part == NULL: dx only)
+  if (part) hipLaunchKernelGGL(ln_c_bwd_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, x, dy, stats, C, HW, planes, part);
   switch (C) {
     case 32:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<32>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate, add); break;
     case 64:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<64>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate, add); break;
@@ -418,6 +419,16 @@ int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int
     default:  hipLaunchKernelGGL(ln_c_bwd_dx, grid, dim3(256), 0, s, x, dy, stats, C, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate, add);
   }
   return check_launch("afd_layernorm_c_bwd");
+}
+
+int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, int accumulate, afd_stream_t st);
+
+int afd_layernorm_c_bwd_params(const float* x, const float* dy, const float* stats, int B, int C, int HW,
+                               float* part, float* dgamma, float* dbeta, int accumulate, afd_stream_t st) {
+  AFD_REQUIRE(x && dy && stats && part && dgamma && dbeta && B > 0 && C > 0 && HW > 0, "afd_layernorm_c_bwd_params: bad argument");
+  const long planes = (long)B * C;
+  hipLaunchKernelGGL(ln_c_bwd_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, as_stream(st), x, dy, stats, C, HW, planes, part);
+  return afd_colsum2(part, dgamma, dbeta, B, C, accumulate, st);
 }
 
 }  // extern "C"

@@ -144,21 +144,29 @@ class _GradMode:
     dependent chain of small dgrad / norm kernels leaves idle.  Legal under stream capture (fork / join by events)."""
     inplace = False
     side = None
-    pending = []          # (x, dy, dw, db, workspace, shape): weight gradients not launched yet
-    launched = []         # the same tuples after launch, held until the join (their buffers are in use on the side stream)
+    pending = []          # (launch closure, tensors it reads): parameter-gradient kernels not launched yet
+    launched = []         # the same pairs after launch, held until the join (their buffers are in use on the side stream)
     batch = 8             # fork the side stream once per this many layers (few cross-stream edges in a captured graph)
 
 
+def defer_to_side_stream(fn, *keep):
+    """Queue fn(stream_handle) -- a launch whose result nothing downstream of backward consumes (a parameter gradient) --
+    for the side stream.  `keep`: the tensors it reads; they are held until the join, so autograd cannot add into them
+    in place and the allocator cannot recycle them while the side stream still reads them."""
+    _GradMode.pending.append((fn, keep))
+    if len(_GradMode.pending) >= _GradMode.batch:
+        flush_wgrads()
+
+
 def flush_wgrads():
-    """Launch the queued weight-gradient kernels on the side stream (one fork for the whole batch)."""
+    """Launch the queued parameter-gradient kernels on the side stream (one fork for the whole batch)."""
     side, q = _GradMode.side, _GradMode.pending
     if not q:
         return
-    L = lib()
     side.wait_stream(torch.cuda.current_stream())                             # fork: every queued dY (and the zeroed .grad) exists
     with torch.cuda.stream(side):
-        for (x, dy, dw, db, ws, (B, Cin, Cout, H, W, ks)) in q:
-            L.afd_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), B, Cin, Cout, H, W, ks, 1, _p(ws), side.cuda_stream)
+        for fn, _ in q:
+            fn(side.cuda_stream)
     _GradMode.launched.extend(q)
     _GradMode.pending = []
 
@@ -441,11 +449,9 @@ class Conv(torch.autograd.Function):
                     L.afd_conv_wgrad(_p(x), _p(dy), _p(wp.grad), _p(bp.grad) if bp is not None else None,
                                      B, Cin, Cout, H, W, ks, 1, _p(ws), _stream())
                 else:
-                    # queued with references to x / dY / workspace: while we hold them autograd cannot add into dY in
-                    # place (it only does so when it owns the last reference) and the allocator cannot hand them out
-                    _GradMode.pending.append((x, dy, wp.grad, bp.grad if bp is not None else None, ws, (B, Cin, Cout, H, W, ks)))
-                    if len(_GradMode.pending) >= _GradMode.batch:
-                        flush_wgrads()
+                    dwp, dbp = _p(wp.grad), (_p(bp.grad) if bp is not None else None)
+                    defer_to_side_stream(lambda st, x=x, dy=dy, ws=ws: L.afd_conv_wgrad(_p(x), _p(dy), dwp, dbp, B, Cin, Cout, H, W, ks, 1,
+                                                                                         _p(ws), st), x, dy, ws)
             else:
                 dw = torch.empty_like(w)
                 db = torch.empty(Cout, device=x.device, dtype=torch.float32) if ctx.has_bias else None
@@ -506,8 +512,20 @@ class LayerNormC(torch.autograd.Function):
         dx = torch.empty_like(x)
         part = torch.empty(B, 2, C, device=x.device, dtype=torch.float32)
         dg, db, acc, (dgamma, dbeta) = _gn_param_targets(C, gamma, ctx.beta_param, x.device)
-        lib().afd_layernorm_c_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(dx), _p(dres), _p(part), _p(dg), _p(db), acc,
-                                  _stream())
+        L = lib()
+        if acc:      # in-place mode: dx now; dgamma / dbeta (plane sums + fold) as a separate call, on the side stream when
+            #            there is one (the same arithmetic either way: the two-stream step stays bit-identical)
+            L.afd_layernorm_c_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(dx), _p(dres), None, None, None, 0, _stream())
+            pdg, pdb = _p(dg), _p(db)
+            params = lambda st, x=x, dy=dy, stats=stats, part=part: L.afd_layernorm_c_bwd_params(
+                _p(x), _p(dy), _p(stats), B, C, H * W, _p(part), pdg, pdb, 1, st)
+            if _GradMode.side is not None:
+                defer_to_side_stream(params, x, dy, stats, part)
+            else:
+                params(_stream())
+            return dx, None, None
+        L.afd_layernorm_c_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(dx), _p(dres), _p(part), _p(dg), _p(db), acc,
+                              _stream())
         return dx, dgamma, dbeta
 
 
@@ -668,6 +686,11 @@ class SiluLinear(torch.autograd.Function):
         dtemb = torch.zeros_like(temb) if ctx.needs_input_grad[0] else None
         wp, bp = ctx.params
         if _direct(wp, bp):
+            if dtemb is None and _GradMode.side is not None:      # parameter gradients only: off the critical path
+                pw, pb = _p(wp.grad), _p(bp.grad)
+                defer_to_side_stream(lambda st, temb=temb, w=w, dout=dout: lib().afd_silu_linear_bwd(
+                    _p(temb), _p(w), _p(dout), pw, pb, None, B, K, N, 1, st), temb, w, dout)
+                return None, None, None
             lib().afd_silu_linear_bwd(_p(temb), _p(w), _p(dout), _p(wp.grad), _p(bp.grad), _p(dtemb), B, K, N, 1, _stream())
             return dtemb, None, None
         dw = torch.empty_like(w)

@@ -165,6 +165,12 @@ int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int
                         float* dgamma_dbeta_partial /* (B,2,C) */,
                         float* dgamma /* (C) or NULL */, float* dbeta /* (C) or NULL */, int accumulate,
                         afd_stream_t stream);
+/* the two halves separately: afd_layernorm_c_bwd with dgamma_dbeta_partial = dgamma = dbeta = NULL writes dx only (the
+ * critical path of backward); this one computes only the parameter gradients (nothing downstream waits for them, so
+ * the host may issue it on another stream) */
+int afd_layernorm_c_bwd_params(const float* x, const float* dy, const float* stats, int B, int C, int HW,
+                               float* dgamma_dbeta_partial /* (B,2,C) */, float* dgamma, float* dbeta, int accumulate,
+                               afd_stream_t stream);
 
 /* ---- F10: multi-head self-attention core (softmax(QK^T/sqrt(d))V), flash-style ------------------
  * ddpm_utils.py:71 (nn.MultiheadAttention, batch_first, 4 heads).  qkv (B,3C,L): channel
