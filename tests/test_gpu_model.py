@@ -287,6 +287,24 @@ def test_sample_999_steps_vs_reference(A):
         assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.01
 
 
+def test_sample_concurrent_equals_one_trajectory_at_a_time(A):
+    """Diffusion.sample_concurrent: the same batches with the same (per batch, per step) noise, run two at a time on two
+    streams or one after the other, give identical images."""
+    afdm, dev = A
+    afdm.set_seed(42)
+    model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device=dev, variant=3).to(dev)
+    diff = afdm.Diffusion(noise_steps=21, img_size=32, device=dev)
+
+    def noise_fn(k, i, shape):
+        g = torch.Generator().manual_seed(1000 * k + i)
+        return torch.randn(shape, generator=g).to(dev)
+
+    xa, ra = diff.sample_concurrent(model, n=10, image_channels=3, batch=4, streams=2, noise_fn=noise_fn)
+    xb, rb = diff.sample_concurrent(model, n=10, image_channels=3, batch=4, streams=1, noise_fn=noise_fn)
+    assert xa.shape == (10, 3, 32, 32) and xa.dtype == torch.uint8 and model.training
+    assert torch.equal(xa, xb) and torch.equal(ra, rb)
+
+
 def test_graph_sampling_equals_eager_sampling(A):
     """One captured denoise step replayed T-2 times must equal the eager loop (same device RNG seed)."""
     afdm, dev = A
