@@ -133,6 +133,37 @@ class Diffusion:
             return xq, rq, x
         return xq, rq
 
+    def sample_rotation_sweep(self, model, n, image_channels, thetas):
+        """Config E sweep (ddpm_tasks.py:346-369) as ONE batched trajectory.  The reference re-seeds before every angle,
+        so every angle consumes the identical noise stream and only the per-step rotation differs: here the
+        len(thetas) * n images ride one batch, every noise draw (x_T from the CPU generator, the per-step noise from the
+        device generator, n images each: the same draws in the same order as one `sample(n, theta)` call after the same
+        seeding) is shared by all angles, and each angle's slice is rotated by its own theta / T after every step.
+        One UNet forward per step instead of len(thetas): at n = 4 the sweep is launch-bound, so this is ~9x faster for
+        the reference's 9 angles.  Returns ([x_u8 per angle], [result_u8 per angle]) like `rotation_results`."""
+        K = len(thetas)
+        model.eval()
+        snaps = [[] for _ in range(K)]
+        with torch.no_grad():
+            x = self._initial_noise(n, image_channels, "reference").repeat(K, 1, 1, 1)
+            for i in reversed(range(1, self.noise_steps)):
+                eps = model(x, self._t_full(K * n, i, x.device))
+                noise = torch.randn(n, *x.shape[1:], device=x.device).repeat(K, 1, 1, 1) if i > 1 else None
+                x = ops.denoise_step(x, eps, noise, self.alpha, self.alpha_hat, self.beta, i)
+                for k, th in enumerate(thetas):
+                    if th:                                   # the reference rotates only for a truthy theta (:375)
+                        x[k * n:(k + 1) * n] = self.rotate_2d_matrix(x[k * n:(k + 1) * n], th / self.noise_steps, self.filter)
+                if i % 100 == 0:
+                    for k in range(K):
+                        snaps[k].append(x[k * n:(k + 1) * n].clone())
+        model.train()
+        xs, results = [], []
+        for k in range(K):
+            xk = x[k * n:(k + 1) * n]
+            xs.append(ops.quantize_u8(xk))
+            results.append(ops.quantize_u8(torch.cat(snaps[k] + [xk])))
+        return xs, results
+
     def sample_concurrent(self, model, n, image_channels, batch=256, streams=2, noise_fn=None):
         """Throughput form of `sample` for many images: the n images are cut into batches of `batch` and `streams`
         of those trajectories run CONCURRENTLY, each on its own HIP stream (the trajectories are independent: sampling

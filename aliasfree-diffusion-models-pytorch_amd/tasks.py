@@ -124,13 +124,9 @@ def _load(model_data):
 def rotation_results(model_data, thatas):
     """Config E sweep (ddpm_tasks.py:346-369): the same seed for every angle, so only the rotation differs."""
     model, diffusion, args = _load(model_data)
-    x_all, results_all = [], []
-    for th in thatas:
-        set_seed(model_data["seed"])
-        x, results = diffusion.sample(model, n=4, image_channels=args.image_channels, theta=th)
-        x_all.append(x)
-        results_all.append(results)
-    return x_all, results_all
+    set_seed(model_data["seed"])
+    # one batched trajectory for all angles (identical noise for every angle, as the reference's per-angle re-seeding gives)
+    return diffusion.sample_rotation_sweep(model, 4, args.image_channels, list(thatas))
 
 
 def shift_results(model_data, shift):

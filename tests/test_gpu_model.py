@@ -287,6 +287,24 @@ def test_sample_999_steps_vs_reference(A):
         assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.01
 
 
+def test_rotation_sweep_equals_one_angle_at_a_time(A):
+    """Config E: the batched sweep against the reference's procedure (re-seed, sample(n, theta)) for each angle."""
+    afdm, dev = A
+    afdm.set_seed(42)
+    model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device=dev, variant=3).to(dev)
+    diff = afdm.Diffusion(noise_steps=201, img_size=32, device=dev)
+    thetas = [-90.0, 0.0, 33.0, 90.0]
+    afdm.set_seed(5)
+    xs, rs = diff.sample_rotation_sweep(model, 3, 3, thetas)
+    for k, th in enumerate(thetas):
+        afdm.set_seed(5)
+        x1, r1 = diff.sample(model, n=3, image_channels=3, theta=th)
+        assert rs[k].shape == r1.shape
+        for got, want in ((xs[k], x1), (rs[k], r1)):
+            d = got.cpu().numpy().astype(int) - want.cpu().numpy().astype(int)
+            assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.01, th
+
+
 def test_sample_concurrent_equals_one_trajectory_at_a_time(A):
     """Diffusion.sample_concurrent: the same batches with the same (per batch, per step) noise, run two at a time on two
     streams or one after the other, give identical images."""
