@@ -722,6 +722,70 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
   }
 }
 
+// the same reduction with 16-byte loads for n % 128 == 0 (every layer but the 3-channel ends): a workgroup owns 128
+// consecutive elements x 8 slab groups, each half-wave streams a 512-byte run of one slab; blocks past n / 128 reduce
+// the bias rows (32 per block) as above.  Fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce4(const float* __restrict__ part, float* __restrict__ dw, long n, int splits,
+                                                     const float* __restrict__ bias_part, float* __restrict__ db, int nb,
+                                                     int accumulate, int T) {
+  __shared__ float4 red4[8][32];
+  const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const long wblocks = n >> 7;
+  if (blockIdx.x < wblocks) {
+    const long j = ((long)blockIdx.x << 7) + 4 * l;
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(part + j);
+    const long stride = n >> 2;
+    float4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int k = g;
+    for (; k + 24 < splits; k += 32) {
+      const float4 a = src[(long)k * stride], b = src[(long)(k + 8) * stride], c = src[(long)(k + 16) * stride],
+                   d = src[(long)(k + 24) * stride];
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+      s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+      s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+      s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+    }
+    for (; k < splits; k += 8) {
+      const float4 a = src[(long)k * stride];
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+    red4[g][l] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                             (s0.w + s1.w) + (s2.w + s3.w));
+    __syncthreads();
+    if (threadIdx.x < 128) {                                  // one element per thread: (float4 slot e >> 2, component e & 3)
+      const int e = threadIdx.x;
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += reinterpret_cast<const float*>(&red4[q][e >> 2])[e & 3];
+      const long je = ((long)blockIdx.x << 7) + e, plane = n / T;
+      float* o = dw + (je % plane) * T + je / plane;
+      *o = accumulate ? *o + t : t;
+    }
+  } else {
+    __shared__ float red[8][33];
+    const long j = (long)(blockIdx.x - wblocks) * 32 + l;
+    float s0 = 0.f;
+    if (j < nb)
+      for (int k = g; k < splits; k += 8) s0 += bias_part[(long)k * nb + j];
+    red[g][l] = s0;
+    __syncthreads();
+    if (g == 0 && j < nb) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[q][l];
+      db[j] = accumulate ? db[j] + t : t;
+    }
+  }
+}
+
+static void launch_wgrad_reduce(const float* part, float* dw, long n, int slabs, const float* bp, float* db, int nb, int accumulate,
+                                int T, hipStream_t s) {
+  if (n % 128 == 0 && (n / T) % 4 == 0)
+    hipLaunchKernelGGL(wgrad_reduce4, dim3((unsigned)(n / 128 + (nb + 31) / 32)), dim3(256), 0, s, part, dw, n, slabs, bp, db, nb, accumulate, T);
+  else
+    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((n + nb + 31) / 32)), dim3(256), 0, s, part, dw, n, slabs, bp, db, nb, accumulate, T);
+}
+
 // ------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------
@@ -954,7 +1018,7 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
     const int slabs = wgrad_wino(x, dy, part, B, Cin, Cout, H, W, s);
     if (slabs) {
       const long n = (long)Cout * Cin * 9;
-      hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, part, dw, n, slabs, nullptr, nullptr, 0, accumulate, 9);
+      launch_wgrad_reduce(part, dw, n, slabs, nullptr, nullptr, 0, accumulate, 9, s);
       return check_launch("afd_conv_wgrad");
     }
   }
@@ -968,8 +1032,7 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
     else if (p.npb == 4) launch_wgrad_roles<9, 4>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
     else if (p.npb == 5) launch_wgrad_roles<9, 5>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
     else launch_wgrad_roles<9, 8>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
-    const long tot = n + (dbias ? Cout : 0);
-    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((tot + 31) / 32)), dim3(256), 0, s, part, dw, n, p.slabs, bp, dbias, dbias ? Cout : 0, accumulate, T);
+    launch_wgrad_reduce(part, dw, n, p.slabs, bp, dbias, dbias ? Cout : 0, accumulate, T, s);
     return check_launch("afd_conv_wgrad");
   } else {
     const dim3 grid((unsigned)(Cout * Cin));
