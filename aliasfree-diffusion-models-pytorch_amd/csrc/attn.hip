@@ -343,8 +343,9 @@ int afd_attn_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d
       else if (g_attn_rows == 4) launch_fwd<8, 4>(qkv, o, lse, B, heads, L, sc, s);
       else launch_fwd<8, 2>(qkv, o, lse, B, heads, L, sc, s);
       break;
-    case 16: launch_fwd<16, 2>(qkv, o, lse, B, heads, L, sc, s); break;
-    case 32: launch_fwd<32, 2>(qkv, o, lse, B, heads, L, sc, s); break;
+    // L <= 64: one row per lane (with two, the second row of every lane would lie past the end of the sequence)
+    case 16: if (L <= 64) launch_fwd<16, 1>(qkv, o, lse, B, heads, L, sc, s); else launch_fwd<16, 2>(qkv, o, lse, B, heads, L, sc, s); break;
+    case 32: if (L <= 64) launch_fwd<32, 1>(qkv, o, lse, B, heads, L, sc, s); else launch_fwd<32, 2>(qkv, o, lse, B, heads, L, sc, s); break;
     default: launch_fwd<64, 1>(qkv, o, lse, B, heads, L, sc, s); break;
   }
   return check_launch("afd_attn_fwd");
@@ -373,8 +374,8 @@ int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float
       else if (g_attn_rows == 4) launch_dq<8, 4>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s);
       else launch_dq<8, 2>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s);
       break;
-    case 16: launch_dq<16, 2>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); break;
-    case 32: launch_dq<32, 2>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); break;
+    case 16: if (L <= 64) launch_dq<16, 1>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); else launch_dq<16, 2>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); break;
+    case 32: if (L <= 64) launch_dq<32, 1>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); else launch_dq<32, 2>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); break;
     default: launch_dq<64, 1>(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s); break;
   }
   switch (d) {      // dK/dV pass (4 vectors per row): 4,4,2,2,1,1
@@ -385,7 +386,7 @@ int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float
       else if (g_attn_rows == 4) launch_dkv<8, 4>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s);
       else launch_dkv<8, 2>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s);
       break;
-    case 16: launch_dkv<16, 2>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s); break;
+    case 16: if (L <= 64) launch_dkv<16, 1>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s); else launch_dkv<16, 2>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s); break;
     case 32: launch_dkv<32, 1>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s); break;
     default: launch_dkv<64, 1>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s); break;
   }

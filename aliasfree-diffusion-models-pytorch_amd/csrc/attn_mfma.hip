@@ -1,8 +1,9 @@
 // attn_mfma.hip -- attention core for head dim 8 (the 16x16 and 32x32 maps: 70 % of attention FLOPs) with
 // the two d-contractions of every pass on the fp32 matrix cores.
 //
-// S^T = K Q^T (and dP^T = V dO^T) are 32x32x2 MFMAs over d = 8 (4 instructions per 32x32 tile).  Their
-// accumulator layout -- lane = query column (l & 31), the 16 registers = 16 of the 32 keys, the other 16 in
+// S^T = K Q^T (and dP^T = V dO^T) are matrix-core products over d = 8 -- at fp32 accuracy on the bf16 path (three
+// v_mfma_f32_32x32x16_bf16 per 32x32 tile on exact three-piece splits of the operands, see split3 below; the one-pass
+// backward still uses four v_mfma_f32_32x32x2_f32).  Their accumulator layout -- lane = query column (l & 31), the 16 registers = 16 of the 32 keys, the other 16 in
 // lane ^ 32 -- is kept for everything that follows: the online softmax is a max over registers plus one
 // cross-half exchange, and the rank-8 products (P V, dS K, P^T dO, dS^T Q) are vector FMAs against LDS rows
 // that both tiles of a wave share.  Compared with the all-VALU kernels this removes 8 of 21 (forward),
@@ -44,12 +45,54 @@ __device__ __forceinline__ void axpy8(f2 (&acc)[4], float s, const f2 (&v)[4]) {
   for (int i = 0; i < 4; ++i) acc[i] = __builtin_elementwise_fma(ss, v[i], acc[i]);
 }
 
+// ---- fp32-accurate d-contractions on the bf16 matrix path ----------------------------------------------------------
+// x = x1 + x2 + x3 exactly (three bf16 pieces, 8 mantissa bits each); the six leading cross terms of a product of two
+// such sums (a1b1, a2b1, a1b2, a3b1, a2b2, a1b3) carry it to 2^-24.  Over d = 8 that is 48 bf16 products per (row,
+// column) pair = THREE 32x32x16 MFMAs whose two lane halves (k = 8 half + d) hold two different terms, against four
+// 32x32x2 fp32 MFMAs.  Measured on MI355X (tools/micro/bf16x3.hip): max error 1.6e-7 of sum|a b| (fp32 MFMA: 1.2e-7)
+// at 0.58x the matrix-pipe time.  The accumulator layout is the fp32 one.
+using bf8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf2 = __attribute__((ext_vector_type(2))) __bf16;
+__device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c) {
+  a = (__bf16)x; const float r = x - (float)a;
+  b = (__bf16)r; const float r2 = r - (float)b;
+  c = (__bf16)r2;
+}
+// B side (the row a lane keeps in registers for the whole kernel): halves (0 | 1) carry  M1: b1 | b1,  M2: b2 | b1,  M3: b2 | b3
+__device__ __forceinline__ void row_frags(const float (&x)[kD], int half, bf8 (&f)[3]) {
+  bf8 p1, p2, p3;
+#pragma unroll
+  for (int d = 0; d < kD; ++d) { __bf16 a, b, c; split3(x[d], a, b, c); p1[d] = a; p2[d] = b; p3[d] = c; }
+  f[0] = p1; f[1] = half ? p1 : p2; f[2] = half ? p3 : p2;
+}
+// A side (the streamed operand): pieces in LDS as [piece][row][8 bf16] (one ds_read_b128 per fragment);
+// halves carry  M1: a1 | a2,  M2: a1 | a3,  M3: a2 | a1.  A thread stages the d-pair (2 jp, 2 jp + 1) of row rr.
+__device__ __forceinline__ void stage_pieces(uint32_t* __restrict__ P, int rr, int jp, float v0, float v1) {
+  __bf16 a0, b0, c0, a1, b1, c1;
+  split3(v0, a0, b0, c0); split3(v1, a1, b1, c1);
+  P[(0 * kTK + rr) * 4 + jp] = __builtin_bit_cast(uint32_t, (bf2){a0, a1});
+  P[(1 * kTK + rr) * 4 + jp] = __builtin_bit_cast(uint32_t, (bf2){b0, b1});
+  P[(2 * kTK + rr) * 4 + jp] = __builtin_bit_cast(uint32_t, (bf2){c0, c1});
+}
+__device__ __forceinline__ void load_frags(const uint32_t* __restrict__ P, int row, int half, bf8 (&a)[3]) {
+  const bf8* p = reinterpret_cast<const bf8*>(P);
+  a[0] = p[(half ? 1 : 0) * kTK + row]; a[1] = p[(half ? 2 : 0) * kTK + row]; a[2] = p[(half ? 0 : 1) * kTK + row];
+}
+__device__ __forceinline__ f32x16 dot8x3(const bf8 (&a)[3], const bf8 (&b)[3]) {
+  f32x16 c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[m], c, 0, 0, 0);
+  return c;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward: workgroup = 256 queries (4 waves x 2 query tiles of 32), streams K/V in tiles of 64 keys
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_fwd_mfma8(const float* __restrict__ qkv, float* __restrict__ o,
                                                       float* __restrict__ lse, int heads, int L, float scale) {
-  __shared__ __attribute__((aligned(16))) float Kd[kD * kTK];       // K, d-major  (MFMA A fragments)
+  __shared__ __attribute__((aligned(16))) uint32_t Kp[3 * kTK * 4];  // K pieces (MFMA A fragments)
   __shared__ __attribute__((aligned(16))) float Vr[kTK * kD];       // V, row-major (P V rows)
   const int b = blockIdx.z, h = blockIdx.y, C = heads * kD;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
@@ -57,11 +100,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma8(const float* __restrict
   const float* kp = qp + (long)C * L;
   const float* vp = kp + (long)C * L;
   const int q0 = blockIdx.x * 256 + wv * 64;                          // this wave's first query
-  float bq[2][4];                                                     // B fragments of the two query tiles
+  bf8 bq[2][3];                                                       // B fragments of the two query tiles
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < 2; ++j) {
+    float x[kD];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bq[j][s] = qp[(long)(2 * s + half) * L + q0 + j * 32 + l31] * (scale * kLog2e);
+    for (int d = 0; d < kD; ++d) x[d] = qp[(long)d * L + q0 + j * 32 + l31] * (scale * kLog2e);
+    row_frags(x, half, bq[j]);
+  }
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
   f2 oa[2][4];
 #pragma unroll
@@ -69,39 +115,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma8(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) oa[j][i] = (f2){0.f, 0.f};
 
-  // the next K / V tile travels global -> registers while the current one is multiplied (2 x 2 values per thread)
+  // the next K / V tile travels global -> registers while the current one is multiplied: a thread owns the d-pair
+  // (2 jp, 2 jp + 1) of row rr (kNE = 2 values per operand)
+  static_assert(kNE == 2, "staging assumes one d-pair per thread");
+  const int jp = threadIdx.x >> 6, rr = threadIdx.x & 63;
   float kreg[kNE], vreg[kNE];
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < kNE; ++e) {
-      const int i = threadIdx.x + 256 * e, j = i / kTK, rr = i % kTK;
-      kreg[e] = kp[(long)j * L + k0 + rr];
-      vreg[e] = vp[(long)j * L + k0 + rr];
+      kreg[e] = kp[(long)(2 * jp + e) * L + k0 + rr];
+      vreg[e] = vp[(long)(2 * jp + e) * L + k0 + rr];
     }
   };
   fetch(0);
   for (int k0 = 0; k0 < L; k0 += kTK) {
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < kNE; ++e) {
-      const int i = threadIdx.x + 256 * e, j = i / kTK, rr = i % kTK;
-      Kd[j * kTK + rr] = kreg[e];
-      Vr[rr * kD + j] = vreg[e];
-    }
+    stage_pieces(Kp, rr, jp, kreg[0], kreg[1]);
+    *reinterpret_cast<float2*>(Vr + rr * kD + 2 * jp) = make_float2(vreg[0], vreg[1]);
     __syncthreads();
     if (k0 + kTK < L) fetch(k0 + kTK);
 #pragma unroll
     for (int kt = 0; kt < kTK / 32; ++kt) {
-      float ak[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) ak[s] = Kd[(2 * s + half) * kTK + kt * 32 + l31];
+      bf8 ak[3];
+      load_frags(Kp, kt * 32 + l31, half, ak);
       f32x16 sc[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[j][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) sc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[s], bq[j][s], sc[j], 0, 0, 0);
+        sc[j] = dot8x3(ak, bq[j]);
         float mx = sc[j][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[j][r]);
@@ -148,8 +188,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma8(const float* __restr
                                                          const float* __restrict__ d_o, const float* __restrict__ lse,
                                                          float* __restrict__ dqkv, float* __restrict__ delta_out,
                                                          int heads, int L, float scale) {
-  __shared__ __attribute__((aligned(16))) float Kd[kD * kTK];
-  __shared__ __attribute__((aligned(16))) float Vd[kD * kTK];
+  __shared__ __attribute__((aligned(16))) uint32_t Kp[3 * kTK * 4];  // K pieces (A fragments of S^T)
+  __shared__ __attribute__((aligned(16))) uint32_t Vp[3 * kTK * 4];  // V pieces (A fragments of dP^T)
   __shared__ __attribute__((aligned(16))) float Kr[kTK * kD];
   const int b = blockIdx.z, h = blockIdx.y, C = heads * kD;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
@@ -158,63 +198,54 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma8(const float* __restr
   const float* vp = kp + (long)C * L;
   const long ob = ((long)b * C + h * kD) * L;
   const int q0 = blockIdx.x * 256 + wv * 64;
-  float bq[2][4], bg[2][4], lsq[2], dlt[2];
+  bf8 bq[2][3], bg[2][3];
+  float lsq[2], dlt[2];
   f2 dq[2][4];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int qi = q0 + j * 32 + l31;
-    float dpart = 0.f;
+    float dpart = 0.f, xq[kD], xg[kD];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int d = 2 * s + half;
-      bq[j][s] = qp[(long)d * L + qi] * (scale * kLog2e);
-      bg[j][s] = d_o[ob + (long)d * L + qi];
-      dpart = fmaf(bg[j][s], o[ob + (long)d * L + qi], dpart);
+    for (int d = 0; d < kD; ++d) {
+      xq[d] = qp[(long)d * L + qi] * (scale * kLog2e);
+      xg[d] = d_o[ob + (long)d * L + qi];
+      dpart = fmaf(xg[d], o[ob + (long)d * L + qi], dpart);
     }
-    dlt[j] = dpart + xhalf(dpart);
+    row_frags(xq, half, bq[j]);
+    row_frags(xg, half, bg[j]);
+    dlt[j] = dpart;
     lsq[j] = lse[((long)b * heads + h) * L + qi] * kLog2e;
     if (half == 0) delta_out[((long)b * heads + h) * L + qi] = dlt[j];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[j][i] = (f2){0.f, 0.f};
   }
+  const int jp = threadIdx.x >> 6, rr = threadIdx.x & 63;      // staging: d-pair (2 jp, 2 jp + 1) of row rr
   float kreg[kNE], vreg[kNE];                           // next K / V tile in flight during the multiplies
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < kNE; ++e) {
-      const int i = threadIdx.x + 256 * e, j = i / kTK, rr = i % kTK;
-      kreg[e] = kp[(long)j * L + k0 + rr];
-      vreg[e] = vp[(long)j * L + k0 + rr];
+      kreg[e] = kp[(long)(2 * jp + e) * L + k0 + rr];
+      vreg[e] = vp[(long)(2 * jp + e) * L + k0 + rr];
     }
   };
   fetch(0);
   for (int k0 = 0; k0 < L; k0 += kTK) {
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < kNE; ++e) {
-      const int i = threadIdx.x + 256 * e, j = i / kTK, rr = i % kTK;
-      Kd[j * kTK + rr] = kreg[e]; Kr[rr * kD + j] = kreg[e];
-      Vd[j * kTK + rr] = vreg[e];
-    }
+    stage_pieces(Kp, rr, jp, kreg[0], kreg[1]);
+    stage_pieces(Vp, rr, jp, vreg[0], vreg[1]);
+    *reinterpret_cast<float2*>(Kr + rr * kD + 2 * jp) = make_float2(kreg[0], kreg[1]);
     __syncthreads();
     if (k0 + kTK < L) fetch(k0 + kTK);
 #pragma unroll
     for (int kt = 0; kt < kTK / 32; ++kt) {
-      float ak[4], av[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        ak[s] = Kd[(2 * s + half) * kTK + kt * 32 + l31];
-        av[s] = Vd[(2 * s + half) * kTK + kt * 32 + l31];
-      }
+      bf8 ak[3], av[3];
+      load_frags(Kp, kt * 32 + l31, half, ak);
+      load_frags(Vp, kt * 32 + l31, half, av);
       f32x16 sc[2], dp[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { sc[j][r] = 0.f; dp[j][r] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          sc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[s], bq[j][s], sc[j], 0, 0, 0);
-          dp[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bg[j][s], dp[j], 0, 0, 0);
-        }
+        sc[j] = dot8x3(ak, bq[j]);
+        dp[j] = dot8x3(av, bg[j]);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -247,8 +278,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma8(const float* __restr
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma8(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           float* __restrict__ dqkv, int heads, int L, float scale) {
-  __shared__ __attribute__((aligned(16))) float Qd[kD * kTK];       // Q, d-major  (A fragments of S)
-  __shared__ __attribute__((aligned(16))) float Gd[kD * kTK];       // dO, d-major (A fragments of dP)
+  __shared__ __attribute__((aligned(16))) uint32_t Qp[3 * kTK * 4];  // Q pieces  (A fragments of S)
+  __shared__ __attribute__((aligned(16))) uint32_t Gp[3 * kTK * 4];  // dO pieces (A fragments of dP)
   __shared__ __attribute__((aligned(16))) float Qr[kTK * kD];       // rows for dK += dS^T Q
   __shared__ __attribute__((aligned(16))) float Gr[kTK * kD];       // rows for dV += P^T dO
   __shared__ float Ls[kTK];
@@ -262,58 +293,61 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma8(const float* __rest
   const float* lp = lse + ((long)b * heads + h) * L;
   const float* dlp = delta + ((long)b * heads + h) * L;
   const int key0 = blockIdx.x * 256 + wv * 64;
-  float bk[2][4], bv[2][4];
+  // B fragments of the wave's two key tiles (K scaled, V): a wave-private LDS image, one ds_read_b128 per fragment and
+  // lane (in registers they cost 48 VGPRs, and the kernel must keep 2 waves / SIMD)
+  __shared__ bf8 Bf[4][2][2][3][64];
   f2 dk[2][4], dv[2][4];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
+    float xk[kD], xv[kD];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bk[j][s] = kp[(long)(2 * s + half) * L + key0 + j * 32 + l31] * (scale * kLog2e);
-      bv[j][s] = vp[(long)(2 * s + half) * L + key0 + j * 32 + l31];
+    for (int d = 0; d < kD; ++d) {
+      xk[d] = kp[(long)d * L + key0 + j * 32 + l31] * (scale * kLog2e);
+      xv[d] = vp[(long)d * L + key0 + j * 32 + l31];
     }
+    bf8 t[3];
+    row_frags(xk, half, t);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) Bf[wv][j][0][m][lane] = t[m];
+    row_frags(xv, half, t);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) Bf[wv][j][1][m][lane] = t[m];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dk[j][i] = (f2){0.f, 0.f}; dv[j][i] = (f2){0.f, 0.f}; }
   }
   float qreg[kNE], greg[kNE], lreg = 0.f, dreg = 0.f;       // next Q / dO / lse / delta tile in flight during the multiplies
+  const int jp = threadIdx.x >> 6, rr = threadIdx.x & 63;      // staging: d-pair (2 jp, 2 jp + 1) of row rr
   auto fetch = [&](int t0) {
 #pragma unroll
     for (int e = 0; e < kNE; ++e) {
-      const int i = threadIdx.x + 256 * e, j = i / kTK, rr = i % kTK;
-      qreg[e] = qp[(long)j * L + t0 + rr];
-      greg[e] = gp[(long)j * L + t0 + rr];
+      qreg[e] = qp[(long)(2 * jp + e) * L + t0 + rr];
+      greg[e] = gp[(long)(2 * jp + e) * L + t0 + rr];
     }
     if (threadIdx.x < kTK) { lreg = lp[t0 + threadIdx.x] * kLog2e; dreg = dlp[t0 + threadIdx.x]; }
   };
   fetch(0);
   for (int t0 = 0; t0 < L; t0 += kTK) {
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < kNE; ++e) {
-      const int i = threadIdx.x + 256 * e, j = i / kTK, rr = i % kTK;
-      Qd[j * kTK + rr] = qreg[e]; Qr[rr * kD + j] = qreg[e];
-      Gd[j * kTK + rr] = greg[e]; Gr[rr * kD + j] = greg[e];
-    }
+    stage_pieces(Qp, rr, jp, qreg[0], qreg[1]);
+    stage_pieces(Gp, rr, jp, greg[0], greg[1]);
+    *reinterpret_cast<float2*>(Qr + rr * kD + 2 * jp) = make_float2(qreg[0], qreg[1]);
+    *reinterpret_cast<float2*>(Gr + rr * kD + 2 * jp) = make_float2(greg[0], greg[1]);
     if (threadIdx.x < kTK) { Ls[threadIdx.x] = lreg; Ds[threadIdx.x] = dreg; }
     __syncthreads();
     if (t0 + kTK < L) fetch(t0 + kTK);
 #pragma unroll
     for (int qt = 0; qt < kTK / 32; ++qt) {
-      float aq[4], ag[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        aq[s] = Qd[(2 * s + half) * kTK + qt * 32 + l31];
-        ag[s] = Gd[(2 * s + half) * kTK + qt * 32 + l31];
-      }
+      bf8 aq[3], ag[3];
+      load_frags(Qp, qt * 32 + l31, half, aq);
+      load_frags(Gp, qt * 32 + l31, half, ag);
       f32x16 sc[2], dp[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        bf8 bkj[3], bvj[3];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sc[j][r] = 0.f; dp[j][r] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          sc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[s], bk[j][s], sc[j], 0, 0, 0);
-          dp[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[s], bv[j][s], dp[j], 0, 0, 0);
-        }
+        for (int m = 0; m < 3; ++m) { bkj[m] = Bf[wv][j][0][m][lane]; bvj[m] = Bf[wv][j][1][m][lane]; }
+        sc[j] = dot8x3(aq, bkj);
+        dp[j] = dot8x3(ag, bvj);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

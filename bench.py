@@ -357,7 +357,7 @@ def main():
                                                 "the Winograd kernels issue 16/36 of those multiplies on the fp32 MFMA, so frac is not bounded by 1")
                                                if name.startswith("conv") else
                                                ("algorithmic attention flops (4*L*L*C forward, 2.5x that backward, SURVEY 8d) / HIP-event time; "
-                                                "fp32 at head dim 8: VALU kernels, priced against the fp32 matrix peak"),
+                                                "fp32 results; head dim 8: d-contractions as 3-piece bf16 splits on the matrix cores (fp32-exact), rank-8 updates and softmax on the vector pipe; priced against the fp32 matrix peak"),
                                       "traffic_source": tsrc}
             else:
                 ach = r["bytes"] / sec / 1e9
