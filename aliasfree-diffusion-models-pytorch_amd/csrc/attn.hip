@@ -54,24 +54,50 @@ template <int P> __device__ __forceinline__ void axpy2(f2 (&acc)[P], float s, co
   for (int i = 0; i < P; ++i) acc[i] = __builtin_elementwise_fma(ss, v[i], acc[i]);
 }
 
-// stage rows [r0, r0+kTile) of a (D, L) j-major operand into LDS as [row][D] (optionally scaled)
-template <int D>
+// stage rows [r0, r0+kTile) of a (D, L) j-major operand into LDS as [row][D] (optionally scaled).  NT = workgroup size:
+// the trip count is a constant, so the loads of a tile are all in flight together (with a run-time bound each load
+// waited for the previous store: at L <= 64, one wave per (batch, head), that latency chain WAS the kernel).
+template <int D, int NT>
 __device__ __forceinline__ void stage_rows(const float* __restrict__ src, float* __restrict__ dst, int r0, int L, float mul) {
-  for (int i = threadIdx.x; i < D * kTile; i += blockDim.x) {
+  constexpr int Q4 = D * kTile / 4;        // float4 slots of a tile
+  if constexpr (Q4 % NT == 0) {
+    if ((L & 3) == 0) {                     // 16-byte loads along the token index (r0 is a multiple of 64)
+      constexpr int CAP = D >= 64 ? 2 : 8;                     // loads in flight (4 registers each; d = 64 has none to spare)
+      constexpr int N4 = Q4 / NT, CH = N4 < CAP ? N4 : CAP;
+#pragma unroll
+      for (int e0 = 0; e0 < N4; e0 += CH) {
+        float4 v[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          const int i = threadIdx.x + NT * (e0 + e), j = i / (kTile / 4), rr = 4 * (i % (kTile / 4));
+          v[e] = (r0 + rr < L) ? *reinterpret_cast<const float4*>(src + (long)j * L + r0 + rr) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          const int i = threadIdx.x + NT * (e0 + e), j = i / (kTile / 4), rr = 4 * (i % (kTile / 4));
+          dst[rr * D + j] = v[e].x * mul; dst[(rr + 1) * D + j] = v[e].y * mul;
+          dst[(rr + 2) * D + j] = v[e].z * mul; dst[(rr + 3) * D + j] = v[e].w * mul;
+        }
+      }
+      return;
+    }
+  }
+#pragma unroll 4
+  for (int i = threadIdx.x; i < D * kTile; i += NT) {
     const int j = i / kTile, rr = i % kTile;
     dst[rr * D + j] = (r0 + rr < L) ? src[(long)j * L + r0 + rr] * mul : 0.f;
   }
 }
 
-template <int D, int R>
-__global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv, float* __restrict__ o,
+template <int D, int R, int NT>
+__global__ __launch_bounds__(NT) void attn_fwd_k(const float* __restrict__ qkv, float* __restrict__ o,
                                                   float* __restrict__ lse, int heads, int L, float scale) {
   constexpr int P = D / 2;
   __shared__ __attribute__((aligned(16))) float Ks[kTile * D];
   __shared__ __attribute__((aligned(16))) float Vs[kTile * D];
   const int b = blockIdx.z, h = blockIdx.y;
   const int C = heads * D;
-  const int q0 = blockIdx.x * blockDim.x * R + threadIdx.x;           // row r of this lane = q0 + r*blockDim
+  const int q0 = blockIdx.x * NT * R + threadIdx.x;           // row r of this lane = q0 + r*blockDim
   const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
   const float* kp = qp + (long)C * L;
   const float* vp = kp + (long)C * L;
@@ -79,7 +105,7 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv,
   float m[R], l[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int qi = q0 + r * blockDim.x;
+    const int qi = q0 + r * NT;
     m[r] = -INFINITY; l[r] = 0.f;
 #pragma unroll
     for (int j = 0; j < D; ++j) q[r][j >> 1][j & 1] = qi < L ? qp[(long)j * L + qi] * (scale * kLog2e) : 0.f;
@@ -88,8 +114,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv,
   }
   for (int k0 = 0; k0 < L; k0 += kTile) {
     __syncthreads();
-    stage_rows<D>(kp, Ks, k0, L, 1.f);
-    stage_rows<D>(vp, Vs, k0, L, 1.f);
+    stage_rows<D, NT>(kp, Ks, k0, L, 1.f);
+    stage_rows<D, NT>(vp, Vs, k0, L, 1.f);
     __syncthreads();
     const int nk = min(kTile, L - k0);
     for (int c0 = 0; c0 < nk; c0 += kChunk) {
@@ -130,7 +156,7 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv,
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int qi = q0 + r * blockDim.x;
+    const int qi = q0 + r * NT;
     if (qi < L) {
       const float inv = 1.0f / l[r];
       float* op = o + ((long)b * C + h * D) * L + qi;
@@ -142,8 +168,8 @@ __global__ __launch_bounds__(256) void attn_fwd_k(const float* __restrict__ qkv,
 }
 
 // dQ: lane = R query rows.  ds = p * (dp - delta) ; dq += ds * k * scale.  Also writes delta for the key pass.
-template <int D, int R>
-__global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ qkv, const float* __restrict__ o,
+template <int D, int R, int NT>
+__global__ __launch_bounds__(NT) void attn_bwd_dq_k(const float* __restrict__ qkv, const float* __restrict__ o,
                                                      const float* __restrict__ d_o, const float* __restrict__ lse,
                                                      float* __restrict__ dqkv, float* __restrict__ delta_out,
                                                      int heads, int L, float scale) {
@@ -152,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
   __shared__ __attribute__((aligned(16))) float Vs[kTile * D];
   const int b = blockIdx.z, h = blockIdx.y;
   const int C = heads * D;
-  const int q0 = blockIdx.x * blockDim.x * R + threadIdx.x;
+  const int q0 = blockIdx.x * NT * R + threadIdx.x;
   const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
   const float* kp = qp + (long)C * L;
   const float* vp = kp + (long)C * L;
@@ -161,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
   float delta[R], ls[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int qi = q0 + r * blockDim.x;
+    const int qi = q0 + r * NT;
     const bool live = qi < L;
     delta[r] = 0.f;
 #pragma unroll
@@ -178,8 +204,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
   }
   for (int k0 = 0; k0 < L; k0 += kTile) {
     __syncthreads();
-    stage_rows<D>(kp, Ks, k0, L, 1.f);
-    stage_rows<D>(vp, Vs, k0, L, 1.f);
+    stage_rows<D, NT>(kp, Ks, k0, L, 1.f);
+    stage_rows<D, NT>(vp, Vs, k0, L, 1.f);
     __syncthreads();
     const int nk = min(kTile, L - k0);
 #pragma unroll 2
@@ -197,7 +223,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int qi = q0 + r * blockDim.x;
+    const int qi = q0 + r * NT;
     if (qi < L) {
       float* dqp = dqkv + ((long)b * 3 * C + h * D) * L + qi;
 #pragma unroll
@@ -207,8 +233,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_k(const float* __restrict__ q
 }
 
 // dK, dV: lane = R key rows; LDS holds a tile of (scale*log2e*Q), dO, lse*log2e and delta rows.
-template <int D, int R>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ qkv, const float* __restrict__ d_o,
+template <int D, int R, int NT>
+__global__ __launch_bounds__(NT) void attn_bwd_dkv_k(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                       float* __restrict__ dqkv, int heads, int L, float scale) {
   constexpr int P = D / 2;
@@ -218,7 +244,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
   __shared__ float Ds[kTile];
   const int b = blockIdx.z, h = blockIdx.y;
   const int C = heads * D;
-  const int kq0 = blockIdx.x * blockDim.x * R + threadIdx.x;
+  const int kq0 = blockIdx.x * NT * R + threadIdx.x;
   const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
   const float* kp = qp + (long)C * L;
   const float* vp = kp + (long)C * L;
@@ -228,7 +254,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
   f2 k[R][P], v[R][P], dk[R][P], dv[R][P];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int ki = kq0 + r * blockDim.x;
+    const int ki = kq0 + r * NT;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       k[r][j >> 1][j & 1] = ki < L ? kp[(long)j * L + ki] : 0.f;
@@ -239,9 +265,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
   }
   for (int t0 = 0; t0 < L; t0 += kTile) {
     __syncthreads();
-    stage_rows<D>(qp, Qs, t0, L, scale * kLog2e);
-    stage_rows<D>(gp, Gs, t0, L, 1.f);
-    for (int i = threadIdx.x; i < kTile; i += blockDim.x) {
+    stage_rows<D, NT>(qp, Qs, t0, L, scale * kLog2e);
+    stage_rows<D, NT>(gp, Gs, t0, L, 1.f);
+    for (int i = threadIdx.x; i < kTile; i += NT) {
       const bool in = t0 + i < L;
       Ls[i] = in ? lp[t0 + i] * kLog2e : INFINITY;     // exp2(s - inf) = 0 for padded queries
       Ds[i] = in ? dlp[t0 + i] : 0.f;
@@ -266,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_k(const float* __restrict__ 
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int ki = kq0 + r * blockDim.x;
+    const int ki = kq0 + r * NT;
     if (ki < L) {
       float* dkp = dqkv + ((long)b * 3 * C + C + h * D) * L + ki;
       float* dvp = dkp + (long)C * L;
@@ -286,17 +312,23 @@ template <int R> static inline void attn_geometry(int B, int heads, int L, dim3&
 }
 template <int D, int R> static void launch_fwd(const float* qkv, float* o, float* lse, int B, int heads, int L, float sc, hipStream_t s) {
   dim3 grid, block; attn_geometry<R>(B, heads, L, grid, block);
-  hipLaunchKernelGGL((attn_fwd_k<D, R>), grid, block, 0, s, qkv, o, lse, heads, L, sc);
+  if (block.x == 64) hipLaunchKernelGGL((attn_fwd_k<D, R, 64>), grid, block, 0, s, qkv, o, lse, heads, L, sc);
+  else if (block.x == 128) hipLaunchKernelGGL((attn_fwd_k<D, R, 128>), grid, block, 0, s, qkv, o, lse, heads, L, sc);
+  else hipLaunchKernelGGL((attn_fwd_k<D, R, 256>), grid, block, 0, s, qkv, o, lse, heads, L, sc);
 }
 template <int D, int R> static void launch_dq(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                                               float* delta, int B, int heads, int L, float sc, hipStream_t s) {
   dim3 grid, block; attn_geometry<R>(B, heads, L, grid, block);
-  hipLaunchKernelGGL((attn_bwd_dq_k<D, R>), grid, block, 0, s, qkv, o, d_o, lse, dqkv, delta, heads, L, sc);
+  if (block.x == 64) hipLaunchKernelGGL((attn_bwd_dq_k<D, R, 64>), grid, block, 0, s, qkv, o, d_o, lse, dqkv, delta, heads, L, sc);
+  else if (block.x == 128) hipLaunchKernelGGL((attn_bwd_dq_k<D, R, 128>), grid, block, 0, s, qkv, o, d_o, lse, dqkv, delta, heads, L, sc);
+  else hipLaunchKernelGGL((attn_bwd_dq_k<D, R, 256>), grid, block, 0, s, qkv, o, d_o, lse, dqkv, delta, heads, L, sc);
 }
 template <int D, int R> static void launch_dkv(const float* qkv, const float* d_o, const float* lse, const float* delta, float* dqkv,
                                                int B, int heads, int L, float sc, hipStream_t s) {
   dim3 grid, block; attn_geometry<R>(B, heads, L, grid, block);
-  hipLaunchKernelGGL((attn_bwd_dkv_k<D, R>), grid, block, 0, s, qkv, d_o, lse, delta, dqkv, heads, L, sc);
+  if (block.x == 64) hipLaunchKernelGGL((attn_bwd_dkv_k<D, R, 64>), grid, block, 0, s, qkv, d_o, lse, delta, dqkv, heads, L, sc);
+  else if (block.x == 128) hipLaunchKernelGGL((attn_bwd_dkv_k<D, R, 128>), grid, block, 0, s, qkv, d_o, lse, delta, dqkv, heads, L, sc);
+  else hipLaunchKernelGGL((attn_bwd_dkv_k<D, R, 256>), grid, block, 0, s, qkv, d_o, lse, delta, dqkv, heads, L, sc);
 }
 
 namespace afd {   // attn_mfma.hip: d = 8 passes with the d-contractions on the matrix cores
