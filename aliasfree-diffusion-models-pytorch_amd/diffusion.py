@@ -164,14 +164,19 @@ class Diffusion:
             results.append(ops.quantize_u8(torch.cat(snaps[k] + [xk])))
         return xs, results
 
-    def sample_concurrent(self, model, n, image_channels, batch=256, streams=2, noise_fn=None):
+    def sample_concurrent(self, model, n, image_channels, batch=256, streams=4, noise_fn=None, graph=False):
         """Throughput form of `sample` for many images: the n images are cut into batches of `batch` and `streams`
         of those trajectories run CONCURRENTLY, each on its own HIP stream (the trajectories are independent: sampling
         is embarrassingly parallel per image).  One 256-image forward leaves CUs idle in its small layers; a second
-        trajectory in flight fills them: measured on MI355X 2 x 256 images on two streams run at 93 images/s against 76
-        for one batch of 256 at a time (a single 512-image batch: 91).  Returns (x_u8, result_u8) like `sample`, batches
-        concatenated.  Noise comes from the device generator (or noise_fn(batch_index, i, x) for tests)."""
+        trajectory in flight fills them: measured on MI355X (tools/sample_streams.py) 77 / 96 / 103 / 107 images/s with
+        1 / 2 / 3 / 4 trajectories of 256 images in flight (a single 512-image batch: 91).  Returns (x_u8, result_u8) like `sample`, batches
+        concatenated.  Noise comes from the device generator (or noise_fn(batch_index, i, x) for tests).
+        graph=True: every trajectory's denoise step (UNet forward + update; the noise is drawn into a static buffer just
+        before) is captured once into its own hipGraph and replayed on its stream, which takes the host's ~170 launches
+        per forward out of the loop."""
         model.eval()
+        if graph:
+            return self._sample_concurrent_graphs(model, n, image_channels, batch, streams, noise_fn)
         sizes = [min(batch, n - o) for o in range(0, n, batch)]
         pool = [torch.cuda.Stream() for _ in range(max(1, min(streams, len(sizes))))]
         cur = torch.cuda.current_stream()
@@ -201,6 +206,67 @@ class Diffusion:
                         snaps[k].append(xs[k])
                         xs_out[k] = ops.quantize_u8(xs[k])
                         snaps_out[k] = ops.quantize_u8(torch.cat(snaps[k]))
+                    cur.wait_stream(pool[k - g0])
+        model.train()
+        for t in xs_out + snaps_out:
+            t.record_stream(cur)
+        return torch.cat(xs_out), torch.cat(snaps_out)
+
+    def _sample_concurrent_graphs(self, model, n, image_channels, batch, streams, noise_fn):
+        sizes = [min(batch, n - o) for o in range(0, n, batch)]
+        pool = [torch.cuda.Stream() for _ in range(max(1, min(streams, len(sizes))))]
+        cur = torch.cuda.current_stream()
+        xs_out, snaps_out = [None] * len(sizes), [None] * len(sizes)
+        shape = (image_channels, self.img_size, self.img_size)
+        slots = {}                                           # (batch size, stream) -> (x, t, noise, graph), captured once
+        with torch.no_grad():
+            for g0 in range(0, len(sizes), len(pool)):
+                group = list(range(g0, min(g0 + len(pool), len(sizes))))
+                state, snaps = {}, {k: [] for k in group}
+                for k in group:
+                    st = pool[k - g0]
+                    st.wait_stream(cur)
+                    key = (sizes[k], k - g0)
+                    with torch.cuda.stream(st):
+                        if key not in slots:
+                            xs = torch.zeros(sizes[k], *shape, device=self.device)
+                            t_dev = torch.full((sizes[k],), self.noise_steps - 1, device=self.device, dtype=torch.long)
+                            nz = torch.zeros_like(xs)
+
+                            def one_step(xs=xs, t_dev=t_dev, nz=nz):
+                                eps = model(xs, t_dev)
+                                ops.denoise_step_dev(xs, eps, nz, self.alpha, self.alpha_hat, self.beta, t_dev, xs)
+                            one_step()                       # warm-up outside capture (allocator, cached weight transforms)
+                            st.synchronize()
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g, stream=st):
+                                one_step()
+                            slots[key] = (xs, t_dev, nz, g)
+                        xs = slots[key][0]
+                        xs.copy_(torch.randn(sizes[k], *shape, device=self.device) if noise_fn is None
+                                 else noise_fn(k, self.noise_steps, (sizes[k], *shape)))
+                    state[k] = slots[key]
+                for i in reversed(range(1, self.noise_steps)):
+                    for k in group:
+                        xs, t_dev, nz, g = state[k]
+                        with torch.cuda.stream(pool[k - g0]):
+                            if i > 1:
+                                t_dev.fill_(i)
+                                if noise_fn is None:
+                                    nz.normal_()
+                                else:
+                                    nz.copy_(noise_fn(k, i, xs.shape))
+                                g.replay()
+                            else:                            # the last step adds no noise (ddpm_models.py:370-373)
+                                eps = model(xs, self._t_full(xs.shape[0], 1, xs.device))
+                                xs.copy_(ops.denoise_step(xs, eps, None, self.alpha, self.alpha_hat, self.beta, 1))
+                            if i % 100 == 0:
+                                snaps[k].append(xs.clone())
+                for k in group:
+                    with torch.cuda.stream(pool[k - g0]):
+                        xs = state[k][0]
+                        xs_out[k] = ops.quantize_u8(xs)
+                        snaps_out[k] = ops.quantize_u8(torch.cat(snaps[k] + [xs]))
                     cur.wait_stream(pool[k - g0])
         model.train()
         for t in xs_out + snaps_out:

@@ -321,6 +321,9 @@ def test_sample_concurrent_equals_one_trajectory_at_a_time(A):
     xb, rb = diff.sample_concurrent(model, n=10, image_channels=3, batch=4, streams=1, noise_fn=noise_fn)
     assert xa.shape == (10, 3, 32, 32) and xa.dtype == torch.uint8 and model.training
     assert torch.equal(xa, xb) and torch.equal(ra, rb)
+    # every trajectory's step replayed from its own hipGraph (batches of 4, 4 and 2: two graphs per stream slot)
+    xc, rc = diff.sample_concurrent(model, n=10, image_channels=3, batch=4, streams=2, noise_fn=noise_fn, graph=True)
+    assert model.training and torch.equal(xa, xc) and torch.equal(ra, rc)
 
 
 def test_graph_sampling_equals_eager_sampling(A):
