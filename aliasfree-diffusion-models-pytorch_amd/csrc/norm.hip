@@ -182,17 +182,31 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ x,
     const float4* r4 = res ? reinterpret_cast<const float4*>(res + b * n) : nullptr;
     float4* o4 = reinterpret_cast<float4*>(dx + b * n);
     const int hw4 = HW >> 2;
-    for (long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-      const int c = (int)(i / hw4);
-      const float g = gamma[c], be = beta[c];
-      const float4 xv = x4[i], dv = d4[i];
-      const float4 rv = r4 ? r4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 o;
-      { const float xh = (xv.x - mean) * rstd; o.x = rstd * (g * gn_dz(xh, dv.x, g, be, rv.x, act) - m1 - xh * m2); }
-      { const float xh = (xv.y - mean) * rstd; o.y = rstd * (g * gn_dz(xh, dv.y, g, be, rv.y, act) - m1 - xh * m2); }
-      { const float xh = (xv.z - mean) * rstd; o.z = rstd * (g * gn_dz(xh, dv.z, g, be, rv.z, act) - m1 - xh * m2); }
-      { const float xh = (xv.w - mean) * rstd; o.w = rstd * (g * gn_dz(xh, dv.w, g, be, rv.w, act) - m1 - xh * m2); }
-      o4[i] = o;
+    constexpr int U = 4;                               // four iterations' loads in flight together (the loop's trip count
+    for (long i0 = lo + threadIdx.x; i0 < hi; i0 += U * blockDim.x) {   // is a run-time value: un-batched, each load waited alone)
+      float4 xv[U], dv[U], rv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long i = i0 + (long)u * blockDim.x;
+        if (i < hi) {
+          xv[u] = x4[i]; dv[u] = d4[i];
+          rv[u] = r4 ? r4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long i = i0 + (long)u * blockDim.x;
+        if (i < hi) {
+          const int c = (int)(i / hw4);
+          const float g = gamma[c], be = beta[c];
+          float4 o;
+          { const float xh = (xv[u].x - mean) * rstd; o.x = rstd * (g * gn_dz(xh, dv[u].x, g, be, rv[u].x, act) - m1 - xh * m2); }
+          { const float xh = (xv[u].y - mean) * rstd; o.y = rstd * (g * gn_dz(xh, dv[u].y, g, be, rv[u].y, act) - m1 - xh * m2); }
+          { const float xh = (xv[u].z - mean) * rstd; o.z = rstd * (g * gn_dz(xh, dv[u].z, g, be, rv[u].z, act) - m1 - xh * m2); }
+          { const float xh = (xv[u].w - mean) * rstd; o.w = rstd * (g * gn_dz(xh, dv[u].w, g, be, rv[u].w, act) - m1 - xh * m2); }
+          o4[i] = o;
+        }
+      }
     }
   } else {
     const long per = (n + gridDim.x - 1) / gridDim.x;
@@ -254,6 +268,52 @@ __global__ __launch_bounds__(256) void ln_c_fwd_reg(const float* __restrict__ x,
   for (int c = 0; c < C; ++c) y[off + (long)c * HW] = (v[c] - mean) * rstd * gamma[c] + beta[c];
 }
 
+// channel-split forward (see ln_c_bwd_dx_split): PX pixels x SPLIT channel groups per workgroup, the pixel's mean and
+// centred variance meet in LDS (two exchanges), the channel slice stays in registers
+template <int C, int SPLIT>
+__global__ __launch_bounds__(256) void ln_c_fwd_split(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ stats,
+                                                      int HW, long pixels, float eps,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta) {
+  constexpr int PX = 256 / SPLIT, CPT = C / SPLIT;
+  __shared__ float ps[2][SPLIT][PX];
+  const int pi = threadIdx.x % PX, g = threadIdx.x / PX;
+  const long p = (long)blockIdx.x * PX + pi;
+  const bool live = p < pixels;
+  float v[CPT];
+  float s = 0.f;
+  long off = 0;
+  if (live) {
+    const long b = p / HW; const int l = p % HW;
+    off = b * (long)C * HW + l;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) { v[i] = x[off + (long)(g + i * SPLIT) * HW]; s += v[i]; }
+  }
+  ps[0][g][pi] = s;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int k = 0; k < SPLIT; ++k) mean += ps[0][k][pi];
+  mean /= (float)C;
+  float s2 = 0.f;
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) { const float d = v[i] - mean; s2 += d * d; }
+  }
+  ps[1][g][pi] = s2;
+  __syncthreads();
+  if (!live) return;
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < SPLIT; ++k) var += ps[1][k][pi];
+  const float rstd = 1.0f / sqrtf(var / (float)C + eps);
+  if (g == 0) { stats[2 * p] = mean; stats[2 * p + 1] = rstd; }
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = g + i * SPLIT;
+    y[off + (long)c * HW] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+  }
+}
+
 __global__ __launch_bounds__(256) void ln_c_bwd_dx(const float* __restrict__ x, const float* __restrict__ dy,
                                                    const float* __restrict__ stats, int C, int HW, long pixels,
                                                    const float* __restrict__ gamma, float* __restrict__ dx,
@@ -304,6 +364,55 @@ __global__ __launch_bounds__(256) void ln_c_bwd_dx_reg(const float* __restrict__
     for (int c = 0; c < C; ++c) {
       const float xh = (x[off + (long)c * HW] - mean) * rstd;
       dx[off + (long)c * HW] = rstd * (g[c] - m1 - xh * m2) + (addp ? addp[off + (long)c * HW] : 0.f);
+    }
+  }
+  if (dgamma) fold_param_grads(part, B, C, dgamma, dbeta, accumulate, red, blockIdx.x, gridDim.x);
+}
+
+// channel-split form: a workgroup = PX pixels x SPLIT channel groups (PX * SPLIT = 256).  One thread per pixel leaves
+// the small maps with 16..64 workgroups, each thread walking 2 C dependent strided loads (47 us for 8.4 MB at 8x8);
+// here a thread owns C / SPLIT channels of its pixel (x and gamma*dy stay in registers: one read of each), the two
+// row sums meet in LDS.  Consecutive threads are consecutive pixels, so loads stay coalesced.
+template <int C, int SPLIT>
+__global__ __launch_bounds__(256) void ln_c_bwd_dx_split(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ stats, int HW, long pixels,
+                                                         const float* __restrict__ gamma, float* __restrict__ dx,
+                                                         const float* __restrict__ part, int B, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, int accumulate, const float* __restrict__ addp) {
+  constexpr int PX = 256 / SPLIT, CPT = C / SPLIT;
+  static_assert(C % SPLIT == 0 && 256 % SPLIT == 0, "bad split");
+  __shared__ float red[16];
+  __shared__ float ps[2][SPLIT][PX];
+  const int pi = threadIdx.x % PX, g = threadIdx.x / PX;
+  const long p = (long)blockIdx.x * PX + pi;
+  const bool live = p < pixels;
+  float gv[CPT], xh[CPT];
+  float s1 = 0.f, s2 = 0.f, rstd = 0.f;
+  long off = 0;
+  if (live) {
+    const long b = p / HW; const int l = p % HW;
+    off = b * (long)C * HW + l;
+    const float mean = stats[2 * p];
+    rstd = stats[2 * p + 1];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = g + i * SPLIT;
+      gv[i] = gamma[c] * dy[off + (long)c * HW];
+      xh[i] = (x[off + (long)c * HW] - mean) * rstd;
+      s1 += gv[i]; s2 += gv[i] * xh[i];
+    }
+  }
+  ps[0][g][pi] = s1; ps[1][g][pi] = s2;
+  __syncthreads();
+  if (live) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < SPLIT; ++k) { t1 += ps[0][k][pi]; t2 += ps[1][k][pi]; }
+    const float m1 = t1 / (float)C, m2 = t2 / (float)C;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const long o = off + (long)(g + i * SPLIT) * HW;
+      dx[o] = rstd * (gv[i] - m1 - xh[i] * m2) + (addp ? addp[o] : 0.f);
     }
   }
   if (dgamma) fold_param_grads(part, B, C, dgamma, dbeta, accumulate, red, blockIdx.x, gridDim.x);
@@ -392,12 +501,17 @@ int afd_layernorm_c_fwd(const float* x, float* y, float* stats_out, int B, int C
   const long pixels = (long)B * HW;
   const dim3 grid((unsigned)((pixels + 255) / 256));
   hipStream_t s = as_stream(st);
+#define AFD_LN_SPLIT(C_, S_) hipLaunchKernelGGL((ln_c_fwd_split<C_, S_>), dim3((unsigned)((pixels + 256 / S_ - 1) / (256 / S_))), dim3(256), 0, s, \
+                                               x, y, stats_out, HW, pixels, eps, gamma, beta)
+#define AFD_LN_BY_PIXELS(C_) do { if (pixels >= 32768) AFD_LN_SPLIT(C_, 4); else if (pixels >= 8192) AFD_LN_SPLIT(C_, 8); else AFD_LN_SPLIT(C_, 16); } while (0)
   switch (C) {
-    case 32:  hipLaunchKernelGGL(ln_c_fwd_reg<32>,  grid, dim3(256), 0, s, x, y, stats_out, HW, pixels, eps, gamma, beta); break;
-    case 64:  hipLaunchKernelGGL(ln_c_fwd_reg<64>,  grid, dim3(256), 0, s, x, y, stats_out, HW, pixels, eps, gamma, beta); break;
-    case 128: hipLaunchKernelGGL(ln_c_fwd_reg<128>, grid, dim3(256), 0, s, x, y, stats_out, HW, pixels, eps, gamma, beta); break;
+    case 32:  AFD_LN_BY_PIXELS(32); break;
+    case 64:  AFD_LN_BY_PIXELS(64); break;
+    case 128: AFD_LN_BY_PIXELS(128); break;
     default:  hipLaunchKernelGGL(ln_c_fwd, grid, dim3(256), 0, s, x, y, stats_out, C, HW, pixels, eps, gamma, beta);
   }
+#undef AFD_LN_BY_PIXELS
+#undef AFD_LN_SPLIT
   return check_launch("afd_layernorm_c_fwd");
 }
 
@@ -412,12 +526,17 @@ int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int
   const dim3 grid((unsigned)((pixels + 255) / 256));
   // plane partials first: the dx kernel's tail folds them into dgamma / dbeta (part == NULL: dx only)
   if (part) hipLaunchKernelGGL(ln_c_bwd_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, x, dy, stats, C, HW, planes, part);
-  switch (C) {
-    case 32:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<32>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate, add); break;
-    case 64:  hipLaunchKernelGGL(ln_c_bwd_dx_reg<64>,  grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate, add); break;
-    case 128: hipLaunchKernelGGL(ln_c_bwd_dx_reg<128>, grid, dim3(256), 0, s, x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate, add); break;
+#define AFD_LN_SPLIT(C_, S_) hipLaunchKernelGGL((ln_c_bwd_dx_split<C_, S_>), dim3((unsigned)((pixels + 256 / S_ - 1) / (256 / S_))), dim3(256), 0, s, \
+                                               x, dy, stats, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate, add)
+#define AFD_LN_BY_PIXELS(C_) do { if (pixels >= 32768) AFD_LN_SPLIT(C_, 4); else if (pixels >= 8192) AFD_LN_SPLIT(C_, 8); else AFD_LN_SPLIT(C_, 16); } while (0)
+  switch (C) {                       // >= 256 workgroups on every map of the UNet (4096 pixels at 4x4: 16 channel groups)
+    case 32:  AFD_LN_BY_PIXELS(32); break;
+    case 64:  AFD_LN_BY_PIXELS(64); break;
+    case 128: AFD_LN_BY_PIXELS(128); break;
     default:  hipLaunchKernelGGL(ln_c_bwd_dx, grid, dim3(256), 0, s, x, dy, stats, C, HW, pixels, gamma, dx, part, B, dgamma, dbeta, accumulate, add);
   }
+#undef AFD_LN_BY_PIXELS
+#undef AFD_LN_SPLIT
   return check_launch("afd_layernorm_c_bwd");
 }
 
