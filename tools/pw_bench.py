@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, afdm, bench
 dev = torch.device("cuda:0"); B = 256
 L, s = afdm.lib(), torch.cuda.current_stream().cuda_stream
+if len(sys.argv) > 1:
+    L.afd_debug_conv_path(int(sys.argv[1]))           # 0 by rule, 1 big tile, 2 split-K small tile, 9 streaming kernel off
 shapes = []
 for (C, S) in bench.ATTN:
     shapes += [(C, 3 * C, S, "in_proj"), (C, C, S, "out/ff")]
