@@ -10,6 +10,7 @@
 // of one image or whole small images, staged into LDS with a zero halo; weights are staged straight
 // from OIHW (no transform pass) into rows of odd stride, which makes every fragment read
 // conflict-free.  fp32 in / fp32 accumulate: bitwise an fma chain, no reduced precision anywhere.
+#include <cstdlib>
 #include "common.h"
 
 namespace afd {
@@ -867,7 +868,8 @@ static inline WgradPlan wgrad_plan(int B, int Cin, int Cout, int H, int W, int k
   p.wk = 4 / (p.wnn * p.wcn);
   p.nchunks = (int)(((long)B * H * W + 63) / 64);
   const long tiles = (long)((Cout + 32 * p.wnn - 1) / (32 * p.wnn)) * ((Cin + 32 * p.wcn - 1) / (32 * p.wcn));
-  long s = 256 / tiles;                     // one workgroup per CU: the kernel is register-heavy (1 wave/SIMD)
+  static const long target = [] { const char* e = getenv("AFD_WG_TARGET"); return e ? atol(e) : 256L; }();   // tuning hook
+  long s = target / tiles;                  // one workgroup per CU: the kernel is register-heavy (1 wave/SIMD)
   if (s < 1) s = 1;
   if (s > p.nchunks) s = p.nchunks;
   p.cps = (int)((p.nchunks + s - 1) / s);

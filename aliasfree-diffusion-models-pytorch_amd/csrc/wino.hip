@@ -14,6 +14,7 @@
 //                  v_mfma_f32_16x16x4_f32 (128 accumulator registers).
 //                  The 16 xi of one (channel, tile) sit in ONE lane, so the output transform A^T M A is
 //                  register arithmetic and the 2x2 results leave as float2 stores.
+#include <cstdlib>
 #include "common.h"
 
 namespace afd {
@@ -781,7 +782,8 @@ int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, in
   const int BN = Cout % 64 == 0 ? 64 : 32, BK = Cin % 64 == 0 ? 64 : 32;
   const int waves = (BN / 32) * (BK / 16);
   const long blocks = (long)(Cout / BN) * (Cin / BK);
-  long s = (256L * (waves == 8 ? 1 : (waves == 4 ? 2 : 4))) / blocks;
+  static const long target = [] { const char* e = getenv("AFD_WGW_TARGET"); return e ? atol(e) : 128L; }();   // tuning hook; 128 measured best (see below)
+  long s = (target * (waves == 8 ? 1 : (waves == 4 ? 2 : 4))) / blocks;
   if (s < 1) s = 1;
   if (s > nch) s = nch;
   const int c = (int)((nch + s - 1) / s);

@@ -148,7 +148,7 @@ class TrainStep:
         if overlap_wgrad is None:
             overlap_wgrad = True
         self.wgrad_stream = torch.cuda.Stream() if overlap_wgrad else None
-        self.wgrad_batch = 16 if graph else 4
+        self.wgrad_batch = int(os.environ.get("AFD_WGRAD_BATCH", 16 if graph else 4))      # layers per fork (tuning hook)
         self.opt = FusedAdamW(model, lr=lr)
         want_ddp = distributed if distributed is not None else dist.is_initialized()
         self.ddp = GradAllReduce(self.opt.fp.grad, n_buckets) if want_ddp else None
@@ -156,6 +156,7 @@ class TrainStep:
         self._graph = None
         self._static = None
         self._wino_plan, self._wino_requests = None, None      # ops.WinoStepPlan after the first (recording) step
+        self._main = torch.cuda.Stream(priority=-1) if (os.environ.get("AFD_MAIN_HP") == "1" and not graph and overlap_wgrad) else None
 
     def _fwd_bwd(self, images, t, eps):
         W = ops._WinoWeights
@@ -194,7 +195,14 @@ class TrainStep:
             t = self.diffusion.sample_timesteps(images.shape[0])
         t = t.to(images.device, non_blocking=True)
         if not self.use_graph:
-            return self._body(images, t, eps)
+            if self._main is None:
+                return self._body(images, t, eps)
+            cur = torch.cuda.current_stream()
+            self._main.wait_stream(cur)
+            with torch.cuda.stream(self._main):           # the dependent chain on a high-priority stream: its kernels
+                loss = self._body(images, t, eps)         # are dispatched ahead of the weight-gradient stream's
+            cur.wait_stream(self._main)
+            return loss
         whole = self.ddp is None                    # single GPU: AdamW is captured too
         if self._graph is None:
             self._static = {"images": images.clone(), "t": t.clone(), "eps": None if eps is None else eps.clone()}
