@@ -144,7 +144,8 @@ class TrainStep:
         # weight-gradient kernels on a second stream (ops._GradMode.side): off the critical path of backward, they fill
         # the CUs the dependent chain of small kernels leaves idle.  Measured on MI355X (B=256): eager 12.0 -> 11.1
         # ms/step, captured graph 11.45 -> 11.3 (forks batched 16 layers at a time: every fork is a cross-stream edge
-        # in the graph, and 57 of them cost more than the overlap returns)
+        # in the graph, and 57 of them cost more than the overlap returns).  Layers per fork, eager: 1 / 2 / 4 / 8 / 16 ->
+        # 9.77 / 9.67 / 9.66 / 9.87 / 9.95 ms.  Stream priorities (side high, or main high) both measured slower.
         if overlap_wgrad is None:
             overlap_wgrad = True
         self.wgrad_stream = torch.cuda.Stream() if overlap_wgrad else None
@@ -156,7 +157,6 @@ class TrainStep:
         self._graph = None
         self._static = None
         self._wino_plan, self._wino_requests = None, None      # ops.WinoStepPlan after the first (recording) step
-        self._main = torch.cuda.Stream(priority=-1) if (os.environ.get("AFD_MAIN_HP") == "1" and not graph and overlap_wgrad) else None
 
     def _fwd_bwd(self, images, t, eps):
         W = ops._WinoWeights
@@ -195,14 +195,7 @@ class TrainStep:
             t = self.diffusion.sample_timesteps(images.shape[0])
         t = t.to(images.device, non_blocking=True)
         if not self.use_graph:
-            if self._main is None:
-                return self._body(images, t, eps)
-            cur = torch.cuda.current_stream()
-            self._main.wait_stream(cur)
-            with torch.cuda.stream(self._main):           # the dependent chain on a high-priority stream: its kernels
-                loss = self._body(images, t, eps)         # are dispatched ahead of the weight-gradient stream's
-            cur.wait_stream(self._main)
-            return loss
+            return self._body(images, t, eps)
         whole = self.ddp is None                    # single GPU: AdamW is captured too
         if self._graph is None:
             self._static = {"images": images.clone(), "t": t.clone(), "eps": None if eps is None else eps.clone()}

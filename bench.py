@@ -356,7 +356,10 @@ def main():
                                       "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3),
                                       "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
                                       "basis": ("algorithmic direct-form flops (2*9*Cin*Cout per output pixel, SURVEY 8d) / HIP-event time; "
-                                                "the Winograd kernels issue 16/36 of those multiplies on the fp32 MFMA, so frac is not bounded by 1")
+                                                "the Winograd kernels issue 16/36 of those multiplies on the fp32 MFMA, so frac is not bounded by 1"
+                                                + ("; weight-gradient launches are sized (128 workgroups) to run on a second stream beside the backward chain "
+                                                   "(whole step 9.83 -> 9.67 ms against 256-workgroup launches), so timed alone, as here, they fill half the CUs"
+                                                   if name == "conv3x3_wgrad" else ""))
                                                if name.startswith("conv") else
                                                ("algorithmic attention flops (4*L*L*C forward, 2.5x that backward, SURVEY 8d) / HIP-event time; "
                                                 "fp32 results; head dim 8: d-contractions as 3-piece bf16 splits on the matrix cores (fp32-exact), rank-8 updates and softmax on the vector pipe; priced against the fp32 matrix peak"),
