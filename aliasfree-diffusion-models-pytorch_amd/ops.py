@@ -66,7 +66,36 @@ class Taps:
 # ---------------------------------------------------------------------------------------------
 # F2 / F3 filtered resampling
 # ---------------------------------------------------------------------------------------------
-class FiltUp2(torch.autograd.Function):
+
+class _NoCtx:
+    """Stand-in for the autograd context when gradients are off (sampling): forward() may set attributes and call
+    save_for_backward; nothing is kept."""
+    needs_input_grad = (False,) * 16
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def mark_dirty(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
+class _Fn(torch.autograd.Function):
+    """autograd.Function whose apply() skips the autograd machinery under no_grad: Function.apply costs ~8 us of host
+    time per call, and with four sampling trajectories in flight (4 x ~130 calls per round) the host is the bound."""
+
+    @classmethod
+    def apply(cls, *args):
+        if torch.is_grad_enabled():
+            return super().apply(*args)
+        return cls.forward(_NoCtx(), *args)
+
+class FiltUp2(_Fn):
     @staticmethod
     def forward(ctx, x, taps):
         _chk(x)
@@ -86,7 +115,7 @@ class FiltUp2(torch.autograd.Function):
         return dx, None
 
 
-class FiltDown2(torch.autograd.Function):
+class FiltDown2(_Fn):
     @staticmethod
     def forward(ctx, x, taps):
         _chk(x)
@@ -111,7 +140,7 @@ def _act_ws(B, C, H, W, N, backward, device):
     return torch.empty(nbytes // 4, device=device, dtype=torch.float32) if nbytes else None
 
 
-class FiltAct(torch.autograd.Function):
+class FiltAct(_Fn):
     """y = down2(GELU(up2(x)))   (ddpm_utils.py:123-125) with no fused prologue."""
 
     @staticmethod
@@ -220,7 +249,7 @@ def _gn_param_targets(C, gamma, beta, device):
     return out[0], out[1], 0, (out[0], out[1])
 
 
-class GroupNorm1(torch.autograd.Function):
+class GroupNorm1(_Fn):
     """y = act(GroupNorm(1,C)(x)*gamma + beta + res) + emb[b,c]      (one HBM round trip)."""
 
     @staticmethod
@@ -254,7 +283,7 @@ class GroupNorm1(torch.autograd.Function):
         return dx, dgamma, dbeta, dres, demb, None
 
 
-class GroupNormFiltAct(torch.autograd.Function):
+class GroupNormFiltAct(_Fn):
     """y = down2(GELU(up2(GroupNorm(1,C)(x)*gamma + beta + res)))    (ddpm_utils.py:122-125,127-131).
 
     Forward: a stats-only pass over x (4 B/elem) then the fused kernel applies the normalisation
@@ -405,7 +434,7 @@ def _conv_fwd(x, w, bias, res, y, B, Cin, Cout, H, W, ks, act, want_dgrad=False)
     return ud
 
 
-class Conv(torch.autograd.Function):
+class Conv(_Fn):
     """y = conv(x, w) + bias + res.  (The GELU epilogue is only used by `conv_infer`.)
 
     fork=True returns (y, x again): the residual branch of a block that STARTS with this convolution takes x from
@@ -492,7 +521,7 @@ def conv_infer(x, w, bias=None, res=None, act=0):
 # ---------------------------------------------------------------------------------------------
 # F10 attention block pieces
 # ---------------------------------------------------------------------------------------------
-class LayerNormC(torch.autograd.Function):
+class LayerNormC(_Fn):
     """nn.LayerNorm([C]) applied to the (B, L, C) token view of an NCHW tensor, without the transposes.
 
     Returns (y, x_res): x_res is x again, for the residual branch that every LayerNorm of the attention block sits
@@ -543,7 +572,7 @@ def layernorm_c(x, gamma, beta):
     return LayerNormC.apply(x, gamma, beta)[0]
 
 
-class Attention(torch.autograd.Function):
+class Attention(_Fn):
     """softmax(QK^T/sqrt(d))V on qkv (B, 3C, H, W) -> (B, C, H, W); scores never materialised."""
 
     @staticmethod
@@ -571,7 +600,7 @@ class Attention(torch.autograd.Function):
         return dqkv, None
 
 
-class Gelu(torch.autograd.Function):
+class Gelu(_Fn):
     @staticmethod
     def forward(ctx, x):
         _chk(x)
@@ -593,7 +622,7 @@ class Gelu(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # resampling of variants 0 / 2, concat
 # ---------------------------------------------------------------------------------------------
-class MaxPool2(torch.autograd.Function):
+class MaxPool2(_Fn):
     @staticmethod
     def forward(ctx, x):
         _chk(x)
@@ -614,7 +643,7 @@ class MaxPool2(torch.autograd.Function):
         return dx
 
 
-class UpCat(torch.autograd.Function):
+class UpCat(_Fn):
     """cat([skip, up2x(x)], dim=1) in one buffer: the upsampler writes straight into the channel
     slice (ddpm_utils.py:241-242 / :354-355 / :413-414).  mode 'filt' = custom_upsample,
     'bilinear' = nn.Upsample(2, bilinear, align_corners=True)."""
@@ -671,7 +700,7 @@ def pos_encoding(t, inv_freq):
     return out
 
 
-class SiluLinear(torch.autograd.Function):
+class SiluLinear(_Fn):
     """emb_layer = nn.Sequential(nn.SiLU(), nn.Linear(emb_dim, C))   (ddpm_utils.py:208-214)."""
 
     @staticmethod
@@ -764,7 +793,7 @@ def rotate_spline3_wrap(x, degrees):
     return y
 
 
-class MseLoss(torch.autograd.Function):
+class MseLoss(_Fn):
     """nn.MSELoss() (mean reduction), deterministic two-stage sum  (ddpm_utils.py:490,503)."""
 
     @staticmethod
