@@ -209,44 +209,75 @@ class _UpStage(_Stage):
         return self.conv[1](self.conv[0](x), self._emb(t))
 
 
-# the reference's class names, as thin constructors over the two stage shells
-def Down(in_channels, out_channels, emb_dim=256):
-    return _DownStage(in_channels, out_channels, emb_dim, None, pooled=True, filtered_act=False)
+# the reference's class names: real nn.Module subclasses of the two stage shells (isinstance / subclassing work as in the
+# reference; the shells hold the one shared implementation)
+class Down(_DownStage):
+    """ddpm_utils.py:199-219."""
+
+    def __init__(self, in_channels, out_channels, emb_dim=256):
+        super().__init__(in_channels, out_channels, emb_dim, None, pooled=True, filtered_act=False)
 
 
-def Down_F(in_channels, out_channels, emb_dim=256, f_settings=None):
-    _design(f_settings)
-    return _DownStage(in_channels, out_channels, emb_dim, f_settings, pooled=True, filtered_act=True)
+class Down_F(_DownStage):
+    """ddpm_utils.py:253-274."""
+
+    def __init__(self, in_channels, out_channels, emb_dim=256, f_settings=None):
+        _design(f_settings)
+        super().__init__(in_channels, out_channels, emb_dim, f_settings, pooled=True, filtered_act=True)
 
 
-def Down_FF(in_channels, out_channels, emb_dim=256, f_settings=None):
-    return _DownStage(in_channels, out_channels, emb_dim, f_settings, pooled=False, filtered_act=False)
+class Down_FF(_DownStage):
+    """ddpm_utils.py:301-328."""
+
+    def __init__(self, in_channels, out_channels, emb_dim=256, f_settings=None):
+        super().__init__(in_channels, out_channels, emb_dim, f_settings, pooled=False, filtered_act=False)
 
 
-def Down_FFF(in_channels, out_channels, emb_dim=256, f_settings=None):
-    return _DownStage(in_channels, out_channels, emb_dim, f_settings, pooled=False, filtered_act=True)
+class Down_FFF(_DownStage):
+    """ddpm_utils.py:360-387."""
+
+    def __init__(self, in_channels, out_channels, emb_dim=256, f_settings=None):
+        super().__init__(in_channels, out_channels, emb_dim, f_settings, pooled=False, filtered_act=True)
 
 
-def Down_F4(in_channels, out_channels, emb_dim=256, f_settings=None):
-    return _DownStage(in_channels, out_channels, emb_dim, f_settings, pooled=False, filtered_act=True, v4=True)
+class Down_F4(_DownStage):
+    """ddpm_utils.py:419-448."""
+
+    def __init__(self, in_channels, out_channels, emb_dim=256, f_settings=None):
+        super().__init__(in_channels, out_channels, emb_dim, f_settings, pooled=False, filtered_act=True, v4=True)
 
 
-def Up(in_channels, out_channels, emb_dim=256):
-    return _UpStage(in_channels, out_channels, emb_dim, None, bilinear=True, filtered_act=False)
+class Up(_UpStage):
+    """ddpm_utils.py:222-245."""
+
+    def __init__(self, in_channels, out_channels, emb_dim=256):
+        super().__init__(in_channels, out_channels, emb_dim, None, bilinear=True, filtered_act=False)
 
 
-def Up_F(in_channels, out_channels, emb_dim=256, f_settings=None):
-    _design(f_settings)
-    return _UpStage(in_channels, out_channels, emb_dim, f_settings, bilinear=True, filtered_act=True)
+class Up_F(_UpStage):
+    """ddpm_utils.py:276-299."""
+
+    def __init__(self, in_channels, out_channels, emb_dim=256, f_settings=None):
+        _design(f_settings)
+        super().__init__(in_channels, out_channels, emb_dim, f_settings, bilinear=True, filtered_act=True)
 
 
-def Up_FF(in_channels, out_channels, emb_dim=256, f_settings=None):
-    return _UpStage(in_channels, out_channels, emb_dim, f_settings, bilinear=False, filtered_act=False)
+class Up_FF(_UpStage):
+    """ddpm_utils.py:330-358."""
+
+    def __init__(self, in_channels, out_channels, emb_dim=256, f_settings=None):
+        super().__init__(in_channels, out_channels, emb_dim, f_settings, bilinear=False, filtered_act=False)
 
 
-def Up_FFF(in_channels, out_channels, emb_dim=256, f_settings=None):
-    return _UpStage(in_channels, out_channels, emb_dim, f_settings, bilinear=False, filtered_act=True)
+class Up_FFF(_UpStage):
+    """ddpm_utils.py:389-417."""
+
+    def __init__(self, in_channels, out_channels, emb_dim=256, f_settings=None):
+        super().__init__(in_channels, out_channels, emb_dim, f_settings, bilinear=False, filtered_act=True)
 
 
-def Up_F4(in_channels, out_channels, emb_dim=256, f_settings=None):
-    return _UpStage(in_channels, out_channels, emb_dim, f_settings, bilinear=False, filtered_act=True, v4=True)
+class Up_F4(_UpStage):
+    """ddpm_utils.py:450-480."""
+
+    def __init__(self, in_channels, out_channels, emb_dim=256, f_settings=None):
+        super().__init__(in_channels, out_channels, emb_dim, f_settings, bilinear=False, filtered_act=True, v4=True)

@@ -311,6 +311,42 @@ int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, in
   hipLaunchKernelGGL(colsum2_k, dim3((2 * C + 31) / 32), dim3(256), 0, as_stream(st), in, out_a, out_b, rows, C, accumulate);
   return check_launch("afd_colsum2");
 }
+// label conditioning (ddpm_models.py:254,276-277): t_emb += label_emb(y)
+__global__ __launch_bounds__(256) void embed_add_fwd_k(const float* __restrict__ temb, const float* __restrict__ table,
+                                                       const int64_t* __restrict__ y, float* __restrict__ out, int B, int D,
+                                                       int K) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i - b * D;
+  long k = y[b];
+  k = k < 0 ? 0 : (k >= K ? K - 1 : k);          // an out-of-range label cannot fault the launch (torch would raise)
+  out[i] = temb[i] + table[k * D + d];
+}
+// one thread per (class, column); the batch is walked in order, so the row sums are deterministic
+__global__ __launch_bounds__(256) void embed_add_bwd_k(const float* __restrict__ dout, const int64_t* __restrict__ y,
+                                                       float* __restrict__ dtable, int B, int D, int K, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= K * D) return;
+  const int k = i / D, d = i - k * D;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    if (y[b] == k) s += dout[(long)b * D + d];
+  dtable[i] = accumulate ? dtable[i] + s : s;
+}
+
+int afd_embed_add_fwd(const float* temb, const float* table, const int64_t* y, float* out, int B, int D, int num_classes,
+                      afd_stream_t st) {
+  AFD_REQUIRE(temb && table && y && out && B > 0 && D > 0 && num_classes > 0, "afd_embed_add_fwd: bad argument");
+  hipLaunchKernelGGL(embed_add_fwd_k, dim3((B * D + 255) / 256), dim3(256), 0, as_stream(st), temb, table, y, out, B, D, num_classes);
+  return check_launch("afd_embed_add_fwd");
+}
+int afd_embed_add_bwd(const float* dout, const int64_t* y, float* dtable, int B, int D, int num_classes, int accumulate,
+                      afd_stream_t st) {
+  AFD_REQUIRE(dout && y && dtable && B > 0 && D > 0 && num_classes > 0, "afd_embed_add_bwd: bad argument");
+  hipLaunchKernelGGL(embed_add_bwd_k, dim3((num_classes * D + 255) / 256), dim3(256), 0, as_stream(st), dout, y, dtable, B, D,
+                     num_classes, accumulate);
+  return check_launch("afd_embed_add_bwd");
+}
 int afd_pos_encoding(const int64_t* t, const float* inv_freq, float* temb, int B, int half, afd_stream_t st) {
   AFD_REQUIRE(t && inv_freq && temb && B > 0 && half > 0, "afd_pos_encoding: bad argument");
   hipLaunchKernelGGL(pos_encoding_k, dim3((B * half + 255) / 256), dim3(256), 0, as_stream(st), t, inv_freq, temb, B, half);

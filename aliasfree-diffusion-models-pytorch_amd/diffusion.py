@@ -10,8 +10,32 @@ import logging
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from . import ops
+
+
+def shard_range(n, rank, world):
+    """Contiguous shard [lo, hi) of n items for `rank` of `world` (sizes differ by at most one; empty when n < world)."""
+    return n * rank // world, n * (rank + 1) // world
+
+
+def gather_u8(t, counts, group=None, dst=0):
+    """Collect every rank's (k_r, ...) uint8 tensor on rank `dst`, concatenated in rank order; `counts[r]` = k_r (known to
+    every rank: shard sizes are a function of n and the world size).  Shards are padded to the largest so one all_gather
+    does it; with 'gloo' the bytes are staged through host memory.  Returns the tensor on `dst`, None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    via_host = dist.get_backend(group) == "gloo"
+    kmax = max(max(counts), 1)
+    pad = torch.zeros((kmax,) + tuple(t.shape[1:]), dtype=torch.uint8, device="cpu" if via_host else t.device)
+    if t.shape[0]:
+        pad[:t.shape[0]].copy_(t)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([parts[r][:counts[r]] for r in range(world)]).to(t.device)
 
 
 class Diffusion:
@@ -41,26 +65,38 @@ class Diffusion:
 
     # F16 ---------------------------------------------------------------------------------
     def _t_full(self, n, i, device):
-        """Device tensor full((n,), i): built once per (n) as arange and sliced -- no per-step H2D."""
-        key = (n, str(device))
+        """Device tensor full((n,), i): built once per (n, stream) as arange and sliced -- no per-step H2D.
+        Keyed by the current HIP stream as well: the table is filled by kernels on the stream that first asks, so a
+        trajectory of `sample_concurrent` on another stream builds (and later frees) its own copy instead of reading one
+        whose fill it is not ordered behind."""
+        key = (n, str(device), ops._stream())
         tab = self._t_cache.get(key)
         if tab is None:
             tab = torch.arange(self.noise_steps, device=device, dtype=torch.long)[:, None].repeat(1, n).contiguous()
-            self._t_cache = {key: tab}
+            if len(self._t_cache) >= 16:
+                self._t_cache.pop(next(iter(self._t_cache)))
+            self._t_cache[key] = tab
         return tab[i]
 
-    def _initial_noise(self, n, c, noise_source):
+    def _initial_noise(self, n, c, noise_source, shard=None):
+        """shard = (lo, hi): draw the noise of all n images (every rank consumes the identical generator stream) and keep
+        rows lo:hi -- a sharded run then produces exactly the images of the one-rank run."""
         shape = (n, c, self.img_size, self.img_size)
         if noise_source == "device":
-            return torch.randn(shape, device=self.device)
-        return torch.randn(shape).to(self.device)                          # reference: CPU draw, then copy (:360)
+            x = torch.randn(shape, device=self.device)
+        else:
+            x = torch.randn(shape).to(self.device)                         # reference: CPU draw, then copy (:360)
+        return x if shard is None else x[shard[0]:shard[1]].contiguous()
 
-    def _step_noise(self, x, noise_source):
+    def _step_noise(self, x, noise_source, shard=None, n=None):
+        shape = x.shape if shard is None else (n,) + tuple(x.shape[1:])
         if noise_source == "cpu":      # parity mode: replay the reference's CPU-path stream
-            return torch.randn(x.shape).to(x.device)
-        return torch.randn_like(x)
+            z = torch.randn(shape).to(x.device)
+        else:
+            z = torch.randn(shape, device=x.device)
+        return z if shard is None else z[shard[0]:shard[1]].contiguous()
 
-    def _loop(self, model, n, image_channels, theta=None, noise_source="reference", graph=None):
+    def _loop(self, model, n, image_channels, theta=None, noise_source="reference", graph=None, shard=None):
         """Shared body of sample / revert.  noise_source: 'reference' (x_T from the CPU generator,
         per-step noise from the device generator -- what the reference does on a GPU), 'cpu'
         (everything from the CPU generator: reproduces the reference's CPU run), 'device'.
@@ -74,16 +110,23 @@ class Diffusion:
         model.eval()
         snaps = []
         with torch.no_grad():
-            x = self._initial_noise(n, image_channels, noise_source)
-            if graph and theta is None and noise_source != "cpu":
+            x = self._initial_noise(n, image_channels, noise_source, shard)
+            n_all, n = n, x.shape[0]
+            if graph and theta is None and noise_source != "cpu" and shard is None:
                 x = self._graph_steps(model, x, snaps)
                 first_eager = 1
             else:
                 first_eager = self.noise_steps - 1
             for i in reversed(range(1, first_eager + 1)):
+                if n == 0:                               # an empty shard still consumes the shared noise stream
+                    if i > 1:
+                        self._step_noise(x, noise_source, shard, n_all)
+                    if i % 100 == 0:
+                        snaps.append(x)
+                    continue
                 t = self._t_full(n, i, x.device)
                 eps = model(x, t)
-                noise = self._step_noise(x, noise_source) if i > 1 else None
+                noise = self._step_noise(x, noise_source, shard, n_all) if i > 1 else None
                 x = ops.denoise_step(x, eps, noise, self.alpha, self.alpha_hat, self.beta, i)
                 if theta_step is not None:
                     x = self.rotate_2d_matrix(x, theta_step, self.filter)
@@ -107,10 +150,12 @@ class Diffusion:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         keep = xs.clone()
+        rng = torch.cuda.get_rng_state(x.device)
         with torch.cuda.stream(side):
             one_step()                                   # warm-up (allocator, lazy init); its effect is undone below
         torch.cuda.current_stream().wait_stream(side)
         xs.copy_(keep)
+        torch.cuda.set_rng_state(rng, x.device)          # ... including its noise draw: the replays consume the stream the eager loop would
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             one_step()
@@ -133,6 +178,54 @@ class Diffusion:
             return xq, rq, x
         return xq, rq
 
+    def sample_sharded(self, model, n, image_channels, theta=None, noise_source="reference", group=None, dst=0):
+        """`sample` with the n images partitioned over the ranks of `group` (sampling is embarrassingly parallel per
+        image: replicas only, no collective in the loop) and the uint8 results gathered on rank `dst`.
+        Every rank must have been seeded alike (as the reference's scripts do with set_seed): each rank draws the noise
+        of ALL n images from the same generator stream and keeps its rows, so the gathered (x, result) equal what one rank
+        computes for the same seed -- whatever the world size.  Returns (x_u8, result_u8) on `dst`, (None, None) elsewhere;
+        without an initialised process group it is `sample`."""
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return self.sample(model, n, image_channels, theta=theta, noise_source=noise_source)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        lo, hi = shard_range(n, rank, world)
+        x, snaps = self._loop(model, n, image_channels, theta, noise_source, None, shard=(lo, hi))
+        counts = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+        xq = gather_u8(ops.quantize_u8(x) if hi > lo else torch.empty((0,) + tuple(x.shape[1:]), dtype=torch.uint8, device=x.device),
+                       counts, group, dst)
+        # result = cat(snapshots): (S * n_r, ...) on each rank -> (S, n, ...) snapshot-major like `sample`
+        S = len(snaps)
+        rq_local = ops.quantize_u8(torch.cat(snaps)) if hi > lo else torch.empty((0,) + tuple(x.shape[1:]), dtype=torch.uint8, device=x.device)
+        rq = gather_u8(rq_local, [S * c for c in counts], group, dst)
+        if rank != dst:
+            return None, None
+        offs = np.cumsum([0] + [S * c for c in counts])
+        per_rank = [rq[offs[r]:offs[r + 1]].reshape(S, counts[r], *rq.shape[1:]) for r in range(world)]
+        return xq, torch.cat(per_rank, dim=1).reshape(S * n, *rq.shape[1:])
+
+    def sample_rotation_sweep_sharded(self, model, n, image_channels, thetas, group=None, dst=0):
+        """Config E sweep (ddpm_tasks.py:346-369) with the ANGLES partitioned over the ranks (BASELINE config 5): each rank
+        runs `sample_rotation_sweep` on its contiguous share of `thetas`; since that draws the n-image noise of every step
+        once and shares it between its angles, all ranks (seeded alike, ddpm_tasks.py:365) consume the identical noise
+        stream however many angles they hold -- "same seed per theta" holds across the shards.  Gathers on `dst`:
+        ([x_u8 per angle], [result_u8 per angle]) in the order of `thetas`; (None, None) elsewhere."""
+        thetas = list(thetas)
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return self.sample_rotation_sweep(model, n, image_channels, thetas)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        K = len(thetas)
+        lo, hi = shard_range(K, rank, world)
+        xs, rs = self.sample_rotation_sweep(model, n, image_channels, thetas[lo:hi])
+        S = (self.noise_steps - 1) // 100 + 1                       # snapshots at i % 100 == 0 (0 < i < T) + the final x
+        shape = (image_channels, self.img_size, self.img_size)
+        empty = torch.empty((0,) + shape, dtype=torch.uint8, device=self.device)
+        counts = [shard_range(K, r, world)[1] - shard_range(K, r, world)[0] for r in range(world)]
+        xa = gather_u8(torch.cat(xs) if xs else empty, [c * n for c in counts], group, dst)
+        ra = gather_u8(torch.cat(rs) if rs else empty, [c * n * S for c in counts], group, dst)
+        if rank != dst:
+            return None, None
+        return list(xa.reshape(K, n, *shape)), list(ra.reshape(K, S * n, *shape))
+
     def sample_rotation_sweep(self, model, n, image_channels, thetas):
         """Config E sweep (ddpm_tasks.py:346-369) as ONE batched trajectory.  The reference re-seeds before every angle,
         so every angle consumes the identical noise stream and only the per-step rotation differs: here the
@@ -142,6 +235,8 @@ class Diffusion:
         One UNet forward per step instead of len(thetas): at n = 4 the sweep is launch-bound, so this is ~9x faster for
         the reference's 9 angles.  Returns ([x_u8 per angle], [result_u8 per angle]) like `rotation_results`."""
         K = len(thetas)
+        if K == 0:                                       # (a rank of the sharded sweep that holds no angle)
+            return [], []
         model.eval()
         snaps = [[] for _ in range(K)]
         with torch.no_grad():

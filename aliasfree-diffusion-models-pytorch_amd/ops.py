@@ -185,13 +185,23 @@ class _GradMode:
     pending = []          # (launch closure, tensors it reads): parameter-gradient kernels not launched yet
     launched = []         # the same pairs after launch, held until the join (their buffers are in use on the side stream)
     batch = 8             # fork the side stream once per this many layers (few cross-stream edges in a captured graph)
+    on_write = None       # callable(list of Parameters): their .grad is complete as far as ENQUEUED work goes -- the
+    #                       data-parallel exchange's readiness hook (training.GradAllReduce.wrote)
 
 
-def defer_to_side_stream(fn, *keep):
+def _wrote(*params):
+    """Report parameters whose gradient the kernels enqueued so far (current stream + side stream) have fully written."""
+    cb = _GradMode.on_write
+    if cb is not None:
+        cb([q for q in params if q is not None])
+
+
+def defer_to_side_stream(fn, *keep, writes=()):
     """Queue fn(stream_handle) -- a launch whose result nothing downstream of backward consumes (a parameter gradient) --
     for the side stream.  `keep`: the tensors it reads; they are held until the join, so autograd cannot add into them
-    in place and the allocator cannot recycle them while the side stream still reads them."""
-    _GradMode.pending.append((fn, keep))
+    in place and the allocator cannot recycle them while the side stream still reads them.  `writes`: the Parameters
+    whose .grad the launch completes (reported to `on_write` once it is launched)."""
+    _GradMode.pending.append((fn, keep, writes))
     if len(_GradMode.pending) >= _GradMode.batch:
         flush_wgrads()
 
@@ -203,19 +213,21 @@ def flush_wgrads():
         return
     side.wait_stream(torch.cuda.current_stream())                             # fork: every queued dY (and the zeroed .grad) exists
     with torch.cuda.stream(side):
-        for fn, _ in q:
+        for fn, _, _ in q:
             fn(side.cuda_stream)
     _GradMode.launched.extend(q)
     _GradMode.pending = []
+    if _GradMode.on_write is not None:
+        _wrote(*[w for _, _, ws in q for w in ws])
 
 
 class inplace_param_grads:
-    def __init__(self, side_stream=None, batch=8):
-        self.side_stream, self.batch = side_stream, batch
+    def __init__(self, side_stream=None, batch=8, on_write=None):
+        self.side_stream, self.batch, self.on_write = side_stream, batch, on_write
 
     def __enter__(self):
-        self.prev, self.prev_side = _GradMode.inplace, _GradMode.side
-        _GradMode.inplace, _GradMode.side, _GradMode.batch = True, self.side_stream, self.batch
+        self.prev, self.prev_side, self.prev_cb = _GradMode.inplace, _GradMode.side, _GradMode.on_write
+        _GradMode.inplace, _GradMode.side, _GradMode.batch, _GradMode.on_write = True, self.side_stream, self.batch, self.on_write
 
     def __exit__(self, exc_type, *a):
         if self.side_stream is not None:
@@ -224,7 +236,7 @@ class inplace_param_grads:
             flush_wgrads()
             torch.cuda.current_stream().wait_stream(self.side_stream)        # join: every dW is in .grad
             _GradMode.launched = []                                          # buffers may be freed now (main-stream order)
-        _GradMode.inplace, _GradMode.side = self.prev, self.prev_side
+        _GradMode.inplace, _GradMode.side, _GradMode.on_write = self.prev, self.prev_side, self.prev_cb
 
 
 def _direct(*params):
@@ -280,6 +292,8 @@ class GroupNorm1(_Fn):
         lib().afd_groupnorm1_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(beta), _p(res), ctx.act,
                                  _p(dx), _p(dres) if (res is not None and ctx.act == 1) else None, _p(part), _p(demb), 0,
                                  _p(dg), _p(db), acc, _stream())
+        if acc:
+            _wrote(gamma, beta)
         return dx, dgamma, dbeta, dres, demb, None
 
 
@@ -322,6 +336,8 @@ class GroupNormFiltAct(_Fn):
         dg, db, acc, (dgamma, dbeta) = _gn_param_targets(C, gamma, beta, x.device)
         L.afd_groupnorm1_bwd(_p(x), _p(dv), _p(stats), B, C, H * W, _p(gamma), _p(beta), None, 0,
                              _p(dx), None, _p(part), None, 1 if fused else 0, _p(dg), _p(db), acc, _stream())
+        if acc:
+            _wrote(gamma, beta)
         return dx, dgamma, dbeta, (dv if res is not None else None), None, None
 
 
@@ -330,11 +346,15 @@ class GroupNormFiltAct(_Fn):
 # ---------------------------------------------------------------------------------------------
 class _WinoWeights:
     """Transformed 3x3 weights (G g G^T, forward and dgrad forms) kept per weight tensor while the weights do not
-    change: keyed by the tensor object, stamped with its autograd version and a global epoch that every raw
-    in-place update of the parameters (FusedAdamW.step) bumps.  Never used under stream capture: a captured step
-    must contain its own transform launches, because a replay runs after the weights moved."""
+    change: keyed by the tensor object AND the HIP stream that asks (the transform launch and every kernel reading the
+    image are then ordered on that one stream: trajectories of `Diffusion.sample_concurrent` running on other streams
+    fill and read their own copies, and an evicted buffer returns to the pool of the only stream that used it),
+    stamped with its autograd version and a global epoch that every raw in-place update of the parameters
+    (FusedAdamW.step) bumps.  Never used under stream capture: a captured step must contain its own transform
+    launches, because a replay runs after the weights moved."""
     epoch = 0
     store = {}
+    max_entries = 4096
     recording = None          # dict filled with the requests of one step (TrainStep's first step), see WinoStepPlan
     active_plan = None        # WinoStepPlan whose buffers were filled at the start of the current step
 
@@ -348,7 +368,7 @@ class _WinoWeights:
         if cls.recording is not None:
             cls.recording.setdefault(id(w), [w, 0, 0])[1 + dgrad] = nbytes
         capturing = torch.cuda.is_current_stream_capturing()
-        key = (id(w), dgrad)
+        key = (id(w), dgrad, _stream())
         stamp = (w._version, cls.epoch, w.data_ptr(), nbytes)
         if not capturing:
             hit = cls.store.get(key)
@@ -356,7 +376,7 @@ class _WinoWeights:
                 return hit[1], 1
         u = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
         if not capturing:
-            if len(cls.store) > 512:
+            if len(cls.store) > cls.max_entries:
                 cls.store.clear()
             try:
                 cls.store[key] = (weakref.ref(w), u, stamp)
@@ -486,10 +506,11 @@ class Conv(_Fn):
                 if side is None:
                     L.afd_conv_wgrad(_p(x), _p(dy), _p(wp.grad), _p(bp.grad) if bp is not None else None,
                                      B, Cin, Cout, H, W, ks, 1, _p(ws), _stream())
+                    _wrote(wp, bp)
                 else:
                     dwp, dbp = _p(wp.grad), (_p(bp.grad) if bp is not None else None)
                     defer_to_side_stream(lambda st, x=x, dy=dy, ws=ws: L.afd_conv_wgrad(_p(x), _p(dy), dwp, dbp, B, Cin, Cout, H, W, ks, 1,
-                                                                                         _p(ws), st), x, dy, ws)
+                                                                                         _p(ws), st), x, dy, ws, writes=(wp, bp))
             else:
                 dw = torch.empty_like(w)
                 db = torch.empty(Cout, device=x.device, dtype=torch.float32) if ctx.has_bias else None
@@ -558,9 +579,10 @@ class LayerNormC(_Fn):
             params = lambda st, x=x, dy=dy, stats=stats, part=part: L.afd_layernorm_c_bwd_params(
                 _p(x), _p(dy), _p(stats), B, C, H * W, _p(part), pdg, pdb, 1, st)
             if _GradMode.side is not None:
-                defer_to_side_stream(params, x, dy, stats, part)
+                defer_to_side_stream(params, x, dy, stats, part, writes=(gamma, ctx.beta_param))
             else:
                 params(_stream())
+                _wrote(gamma, ctx.beta_param)
             return dx, None, None
         L.afd_layernorm_c_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(dx), _p(dres), _p(part), _p(dg), _p(db), acc,
                               _stream())
@@ -700,6 +722,44 @@ def pos_encoding(t, inv_freq):
     return out
 
 
+class EmbedAdd(_Fn):
+    """t_emb + label_emb(y)  (ddpm_models.py:276-277): nn.Embedding lookup and the add in one launch; backward is the
+    deterministic row scatter into the table's gradient (the positional encoding itself carries no gradient)."""
+
+    @staticmethod
+    def forward(ctx, temb, table, y):
+        _chk(temb, table)
+        if not y.is_cuda or y.dtype != torch.long:
+            raise AfdError("afdm: class labels must be an int64 tensor on the HIP device")
+        temb, table, y = _c(temb), _c(table), _c(y)
+        B, D = temb.shape
+        if table.shape[1] != D or y.shape[0] != B:
+            raise AfdError(f"afdm: label embedding shape mismatch (temb {tuple(temb.shape)}, table {tuple(table.shape)}, y {tuple(y.shape)})")
+        out = torch.empty_like(temb)
+        lib().afd_embed_add_fwd(_p(temb), _p(table), _p(y), _p(out), B, D, table.shape[0], _stream())
+        ctx.save_for_backward(y)
+        ctx.table = table if isinstance(table, torch.nn.Parameter) else None
+        ctx.K = table.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (y,) = ctx.saved_tensors
+        dout = _c(dout)
+        B, D = dout.shape
+        dtemb = dout if ctx.needs_input_grad[0] else None
+        if not ctx.needs_input_grad[1]:
+            return dtemb, None, None
+        tp = ctx.table
+        if tp is not None and _direct(tp):
+            lib().afd_embed_add_bwd(_p(dout), _p(y), _p(tp.grad), B, D, ctx.K, 1, _stream())
+            _wrote(tp)
+            return dtemb, None, None
+        dtable = torch.empty(ctx.K, D, device=dout.device, dtype=torch.float32)
+        lib().afd_embed_add_bwd(_p(dout), _p(y), _p(dtable), B, D, ctx.K, 0, _stream())
+        return dtemb, dtable, None
+
+
 class SiluLinear(_Fn):
     """emb_layer = nn.Sequential(nn.SiLU(), nn.Linear(emb_dim, C))   (ddpm_utils.py:208-214)."""
 
@@ -727,9 +787,10 @@ class SiluLinear(_Fn):
             if dtemb is None and _GradMode.side is not None:      # parameter gradients only: off the critical path
                 pw, pb = _p(wp.grad), _p(bp.grad)
                 defer_to_side_stream(lambda st, temb=temb, w=w, dout=dout: lib().afd_silu_linear_bwd(
-                    _p(temb), _p(w), _p(dout), pw, pb, None, B, K, N, 1, st), temb, w, dout)
+                    _p(temb), _p(w), _p(dout), pw, pb, None, B, K, N, 1, st), temb, w, dout, writes=(wp, bp))
                 return None, None, None
             lib().afd_silu_linear_bwd(_p(temb), _p(w), _p(dout), _p(wp.grad), _p(bp.grad), _p(dtemb), B, K, N, 1, _stream())
+            _wrote(wp, bp)
             return dtemb, None, None
         dw = torch.empty_like(w)
         db = torch.empty(N, device=w.device, dtype=torch.float32)

@@ -122,11 +122,13 @@ def _load(model_data):
 
 
 def rotation_results(model_data, thatas):
-    """Config E sweep (ddpm_tasks.py:346-369): the same seed for every angle, so only the rotation differs."""
+    """Config E sweep (ddpm_tasks.py:346-369): the same seed for every angle, so only the rotation differs.
+    One batched trajectory for all angles (identical noise for every angle, as the reference's per-angle re-seeding gives);
+    under torch.distributed the angles are partitioned over the ranks and rank 0 gets the gathered lists (the other ranks
+    get (None, None)) -- BASELINE config 5."""
     model, diffusion, args = _load(model_data)
     set_seed(model_data["seed"])
-    # one batched trajectory for all angles (identical noise for every angle, as the reference's per-angle re-seeding gives)
-    return diffusion.sample_rotation_sweep(model, 4, args.image_channels, list(thatas))
+    return diffusion.sample_rotation_sweep_sharded(model, 4, args.image_channels, list(thatas))
 
 
 def shift_results(model_data, shift):

@@ -45,17 +45,24 @@ def setup_logging(run_name):
 
 
 class FlatParams:
-    """Re-homes a model's parameters (and their .grad) as views of two flat fp32 buffers, in
-    `parameters()` order, so the optimiser is one kernel launch and the DDP exchange is a handful of
-    large all-reduces.  state_dict()/load_state_dict() keep working (the Parameters are the same
-    objects; only their storage moved)."""
+    """Re-homes a model's parameters (and their .grad) as views of two flat fp32 buffers so the optimiser is one
+    kernel launch and the DDP exchange is a handful of large all-reduces.  Order: `parameters()` order, except that
+    parameters the forward never touches (`model.unused_parameters()`, e.g. variant 4's stage-level `norm1` or
+    `label_emb` of an unconditionally trained net) sit at the tail, beyond `n_active`: the reference's
+    `torch.optim.AdamW` skips parameters whose grad is None (ddpm_utils.py:489,504-506 after `zero_grad()`), so they
+    must see neither the update nor the weight decay.  state_dict()/load_state_dict() keep working (the Parameters are
+    the same objects; only their storage moved)."""
 
     def __init__(self, model):
         params = [p for p in model.parameters()]
         assert params and all(p.dtype == torch.float32 for p in params)
+        unused = getattr(model, "unused_parameters", None)
+        skip = {id(p) for p in unused()} if callable(unused) else set()
+        params = [p for p in params if id(p) not in skip] + [p for p in params if id(p) in skip]
         dev = params[0].device
         self.params = params
         self.numel = sum(p.numel() for p in params)
+        self.n_active = sum(p.numel() for p in params if id(p) not in skip)
         self.flat = torch.empty(self.numel, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
         self.offsets = []
@@ -77,7 +84,8 @@ class FlatParams:
 
 class FusedAdamW:
     """torch.optim.AdamW(params, lr) semantics (betas .9/.999, eps 1e-8, weight_decay 0.01 --
-    the defaults the reference relies on, ddpm_utils.py:489) as ONE kernel over the flat buffers.
+    the defaults the reference relies on, ddpm_utils.py:489) as ONE kernel over the flat buffers (their first
+    `n_active` elements: see FlatParams).
     The step counter and bias corrections live on the device so a captured hipGraph replays correctly."""
 
     def __init__(self, model_or_flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
@@ -92,43 +100,135 @@ class FusedAdamW:
         self.fp.zero_grad()
 
     def step(self, grad_scale=1.0):
-        L, s = lib(), torch.cuda.current_stream().cuda_stream
+        L, s = lib(), ops._stream()
         L.afd_adamw_tick(self.state.data_ptr(), self.betas[0], self.betas[1], s)
         L.afd_adamw_step(self.fp.flat.data_ptr(), self.fp.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                         self.fp.numel, self.state.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps,
+                         self.fp.n_active, self.state.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps,
                          self.weight_decay, grad_scale, s)
         ops.bump_param_epoch()                          # the parameters moved under raw pointers: cached transforms are stale
 
 
 class GradAllReduce:
-    """Data-parallel gradient exchange: SUM all-reduce of the flat gradient buffer in `n_buckets`
-    contiguous slices (a few MB each: xGMI rings are per-link bound, so few large messages), the mean
-    is folded into AdamW's grad_scale.  Works on any torch.distributed backend: 'nccl' (= RCCL over
-    xGMI) on GPUs; with 'gloo' the slices are staged through host memory (used by the CPU tests and
-    when several ranks share one GPU)."""
+    """Data-parallel gradient exchange: SUM all-reduce of the flat gradient buffer in a few contiguous buckets (a few MB
+    each: xGMI rings are per-link bound, so few large messages), the mean folded into AdamW's grad_scale.
 
-    def __init__(self, flat_grad, n_buckets=4, group=None):
-        self.g, self.group = flat_grad, group
+    Overlap with backward: backward produces parameter gradients in reverse layer order, i.e. from the END of the flat
+    buffer.  Every op that writes a parameter's gradient reports it (`wrote`, wired to ops._GradMode.on_write by
+    TrainStep; launches deferred to the weight-gradient stream report when they are actually launched); when the last
+    parameter of a bucket has been written, a communication stream waits for the streams that wrote into the bucket
+    (events) and the bucket's all-reduce starts there while backward goes on with the earlier layers.  `finish()` joins
+    them before AdamW (and exchanges whatever was not reported, e.g. after a hipGraph replay of the backward).
+    Buckets are cut at top-level module boundaries walking the model backwards (for the UNet: [up1..outc], [bot2,bot3],
+    [down3,sa3,bot1], [inc..sa2]: the last one to become ready is the smallest, 2.2 MB).
+
+    Works on any torch.distributed backend: 'nccl' (= RCCL over xGMI) on GPUs; with 'gloo' and device tensors each
+    bucket is staged through host memory (CPU tests, several ranks sharing one GPU)."""
+
+    def __init__(self, flat, n_buckets=4, group=None, model=None):
+        fp = flat if isinstance(flat, FlatParams) else None
+        self.g = fp.grad[:fp.n_active] if fp is not None else flat
+        self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        n = flat_grad.numel()
+        n = self.g.numel()
         nb = max(1, min(n_buckets, n))
-        edges = [n * i // nb for i in range(nb + 1)]
-        self.slices = [(edges[i], edges[i + 1]) for i in range(nb) if edges[i + 1] > edges[i]]
-        self.via_host = dist.is_initialized() and dist.get_backend(group) == "gloo" and flat_grad.is_cuda
+        edges = None
+        if fp is not None and model is not None:
+            edges = self._module_edges(fp, model, nb)
+        if edges is None:
+            edges = [n * i // nb for i in range(nb + 1)]
+        self.slices = [(edges[i], edges[i + 1]) for i in range(len(edges) - 1) if edges[i + 1] > edges[i]]
+        self.via_host = dist.is_initialized() and dist.get_backend(group) == "gloo" and self.g.is_cuda
+        self.comm = torch.cuda.Stream() if self.g.is_cuda else None
+        self.side = None                                # the weight-gradient stream (set by TrainStep)
+        # parameter -> bucket, for the readiness bookkeeping
+        self._bucket_of, self._count = {}, [0] * len(self.slices)
+        if fp is not None:
+            for p_, o in zip(fp.params, fp.offsets):
+                if o >= fp.n_active:
+                    continue
+                k = next(i for i, (a, b) in enumerate(self.slices) if a <= o < b)
+                assert o + p_.numel() <= self.slices[k][1], "a parameter straddles two buckets"
+                self._bucket_of[id(p_)] = k
+                self._count[k] += 1
+        self._left, self._seen, self._works, self._launched = list(self._count), set(), [], set()
+        self.overlapped_last_step = 0
 
-    def __call__(self):
+    @staticmethod
+    def _module_edges(fp, model, nb):
+        """Bucket edges at top-level module boundaries, accumulating from the last module backwards."""
+        kids = [m for m in model.children() if any(True for _ in m.parameters())]
+        off = {id(p_): o for p_, o in zip(fp.params, fp.offsets)}
+        starts = []
+        for m in kids:
+            os_ = [off[id(p_)] for p_ in m.parameters() if off[id(p_)] < fp.n_active]
+            if os_:
+                starts.append(min(os_))
+        if len(starts) < 2 or starts != sorted(starts) or starts[0] != 0:
+            return None
+        target, edges, hi = fp.n_active / nb, [fp.n_active], fp.n_active
+        for st in reversed(starts[1:]):
+            if hi - st >= target and len(edges) < nb:
+                edges.append(st)
+                hi = st
+        edges.append(0)
+        return sorted(set(edges))
+
+    # -- readiness bookkeeping (called during backward) ------------------------------------------
+    def begin_step(self):
+        self._left, self._seen, self._works, self._launched = list(self._count), set(), [], set()
+
+    def wrote(self, params):
+        """The gradient of each given parameter has been fully written by work already ENQUEUED on the current stream or on
+        the weight-gradient stream."""
+        if self.world == 1:
+            return
+        for p_ in params:
+            k = self._bucket_of.get(id(p_))
+            if k is None or id(p_) in self._seen:
+                continue
+            self._seen.add(id(p_))
+            self._left[k] -= 1
+            if self._left[k] == 0:
+                self._launch(k)
+
+    def _launch(self, k):
+        if k in self._launched:
+            return
+        self._launched.add(k)
+        a, b = self.slices[k]
+        buf = self.g[a:b]
+        if self.comm is None:                            # CPU tensors (gloo): plain async all-reduce
+            self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+            return
+        self.comm.wait_stream(torch.cuda.current_stream())
+        if self.side is not None:
+            self.comm.wait_stream(self.side)
+        with torch.cuda.stream(self.comm):
+            if self.via_host:
+                h = buf.to("cpu", non_blocking=False)
+                self._works.append((dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group, async_op=True), h, buf))
+            else:
+                self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+
+    def finish(self):
+        """Exchange every bucket not started yet, wait for all of them; returns the factor that turns the summed gradient
+        into the mean (handed to AdamW as grad_scale)."""
         if self.world == 1:
             return 1.0
-        if self.via_host:
-            h = self.g.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
-            self.g.copy_(h)
-        else:
-            works = [dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                     for a, b in reversed(self.slices)]          # last layers' grads are ready first
-            for w in works:
-                w.wait()
+        self.overlapped_last_step = len(self._launched)
+        for k in reversed(range(len(self.slices))):      # last layers first
+            self._launch(k)
+        for w, h, buf in self._works:
+            w.wait()                                     # nccl: the current stream waits for the collective
+            if h is not None:
+                buf.copy_(h)
+        self._works = []
         return 1.0 / self.world
+
+    def __call__(self):
+        """Whole exchange at once (no overlap): every bucket, last layers first."""
+        self.begin_step()
+        return self.finish()
 
 
 class TrainStep:
@@ -152,7 +252,10 @@ class TrainStep:
         self.wgrad_batch = int(os.environ.get("AFD_WGRAD_BATCH", 16 if graph else 4))      # layers per fork (tuning hook)
         self.opt = FusedAdamW(model, lr=lr)
         want_ddp = distributed if distributed is not None else dist.is_initialized()
-        self.ddp = GradAllReduce(self.opt.fp.grad, n_buckets) if want_ddp else None
+        self.ddp = GradAllReduce(self.opt.fp, n_buckets, model=model) if want_ddp else None
+        if self.ddp is not None:
+            self.ddp.side = self.wgrad_stream
+        self._loss_work = None
         self.use_graph = graph
         self._graph = None
         self._static = None
@@ -170,7 +273,11 @@ class TrainStep:
             pred = self.model(x_t, t)
             loss = ops.mse_loss(noise, pred)
             self.opt.zero_grad()
-            with ops.inplace_param_grads(self.wgrad_stream, self.wgrad_batch):   # weight gradients add straight into the flat .grad views
+            overlap = self.ddp is not None and self.ddp.world > 1 and not self.use_graph      # (a captured backward cannot hold the exchange)
+            if overlap:
+                self.ddp.begin_step()                  # bucket all-reduces start during backward, as their gradients complete
+            with ops.inplace_param_grads(self.wgrad_stream, self.wgrad_batch,   # weight gradients add straight into the flat .grad views
+                                         on_write=self.ddp.wrote if overlap else None):
                 loss.backward()
         finally:
             if W.recording is not None and W.recording is self._wino_requests:
@@ -180,7 +287,7 @@ class TrainStep:
         return loss.detach()
 
     def _update(self):
-        scale = self.ddp() if self.ddp is not None else 1.0
+        scale = self.ddp.finish() if self.ddp is not None else 1.0
         self.opt.step(grad_scale=scale)
 
     def _body(self, images, t, eps):
@@ -200,16 +307,30 @@ class TrainStep:
         if self._graph is None:
             self._static = {"images": images.clone(), "t": t.clone(), "eps": None if eps is None else eps.clone()}
             st = self._static
+            # warm-up outside capture (allocator, lazy init, the Winograd plan's recording step).  These are real steps on
+            # the first batch, so everything they change is put back afterwards -- parameters, AdamW moments and step
+            # counter, the device generator -- and under data parallel they stop before the exchange: the first graph
+            # call is then exactly one step, like the eager one (and like the reference's).
+            fp, opt = self.opt.fp, self.opt
+            keep = [b.clone() for b in (fp.flat, opt.m, opt.v, opt.state)]
+            rng = torch.cuda.get_rng_state(images.device)
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                for _ in range(2):                      # warm-up outside capture (allocator, lazy init)
-                    self._body(st["images"], st["t"], st["eps"])
+                for _ in range(2):
+                    (self._body if whole else self._fwd_bwd)(st["images"], st["t"], st["eps"])
             torch.cuda.current_stream().wait_stream(s)
+            for b, k in zip((fp.flat, opt.m, opt.v, opt.state), keep):
+                b.copy_(k)
+            torch.cuda.set_rng_state(rng, images.device)
+            ops.bump_param_epoch()
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 st["loss"] = (self._body if whole else self._fwd_bwd)(st["images"], st["t"], st["eps"])
         st = self._static
+        if (eps is None) != (st["eps"] is None):
+            raise ValueError("TrainStep(graph=True): the step was captured " + ("without" if st["eps"] is None else "with") +
+                             " injected noise; `eps` must be passed (or omitted) on every call alike")
         st["images"].copy_(images)
         st["t"].copy_(t)
         if eps is not None:
@@ -217,6 +338,7 @@ class TrainStep:
         self._graph.replay()
         ops.bump_param_epoch()                          # the replayed AdamW moved the parameters
         if not whole:
+            self.ddp.begin_step()                       # the replayed backward reported nothing: exchange everything now
             self._update()
         return st["loss"]
 

@@ -66,6 +66,18 @@ class UNet(nn.Module):
             print("Unconditional UNet")
         self._inv_freq = None
 
+    def unused_parameters(self, conditional=False):
+        """Parameters `forward(x, t)` never touches, so their grad stays None in the reference and its AdamW skips them:
+        variant 4's stage-level `norm1` (constructed, never called: ddpm_utils.py:440,445,471,476) and `label_emb` when no
+        labels are passed (ddpm_models.py:276-277; the reference's train loop never passes any, ddpm_utils.py:502)."""
+        out = []
+        if self.variant == 4:
+            for st in (self.down1, self.down2, self.down3, self.up1, self.up2, self.up3):
+                out += list(st.norm1.parameters())
+        if hasattr(self, "label_emb") and not conditional:
+            out += list(self.label_emb.parameters())
+        return out
+
     # -- time embedding ---------------------------------------------------------------------
     def _inv_freq_on(self, device):
         if self._inv_freq is None or self._inv_freq.device != device:
@@ -89,7 +101,7 @@ class UNet(nn.Module):
             raise ops.AfdError("afdm.UNet: the HIP engine has no CPU path; move the model and inputs to 'cuda'")
         t = self.pos_encoding(t.to(x.device), self.time_dim)
         if y is not None:
-            t = t + self.label_emb(y)
+            t = ops.EmbedAdd.apply(t, self.label_emb.weight, y.to(x.device))        # t += label_emb(y)   (:276-277)
         x1 = self.inc(x)
         x2 = self.sa1(self.down1(x1, t))
         x3 = self.sa2(self.down2(x2, t))

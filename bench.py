@@ -165,43 +165,82 @@ def pmc_traffic(family, launches):
         return None, None
 
 
-def cpu_baseline(steps=6, B=64):
-    """The CPU oracle's train step (fwd + autograd bwd + AdamW) on the host cores, Config D, a bounded
-    sample of the same workload (B=64 instead of 256 per step; ~10-20 s of CPU work)."""
+def _cpu_train_leg(variant, c, B, steps):
+    """The CPU oracle's train step (fwd + autograd bwd + AdamW) on the host cores: (images/s, s/step)."""
     import contextlib, io
     import afdm
     from oracle import ref_ops as R
-    torch.set_num_threads(host_threads())
     afdm.set_seed(42)
     with contextlib.redirect_stdout(io.StringIO()):
-        net = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device="cpu", variant=3)
+        net = afdm.UNet(c_in=c, c_out=c, image_size=32, f_settings=dict(F_SET) if variant else None, device="cpu", variant=variant)
     sd = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
     m = {k: torch.zeros_like(v) for k, v in sd.items()}
     v2 = {k: torch.zeros_like(v) for k, v in sd.items()}
     _, _, ah = R.noise_schedule(1000)
     g = torch.Generator().manual_seed(42)
-    images = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    images = torch.rand(B, c, 32, 32, generator=g) * 2 - 1
     times = []
     for it in range(steps + 1):
         t0 = time.perf_counter()
         t = torch.randint(1, 1000, (B,))
         eps = torch.randn(images.shape)
-        _, _, grads = R.train_step_loss_and_grads(sd, images, t, eps, 3, F_SET, ah)
+        _, _, grads = R.train_step_loss_and_grads(sd, images, t, eps, variant, F_SET, ah)
         with torch.no_grad():
             for kname in sd:
                 p, m[kname], v2[kname] = R.adamw_step(sd[kname], grads[kname], m[kname], v2[kname], it + 1, 3e-4)
                 sd[kname].copy_(p)
         times.append(time.perf_counter() - t0)
     dt = sum(times[1:]) / steps
-    return {"value": round(B / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"CPU oracle (oracle/ref_ops.py, torch-CPU fp32) train step, Config D, B={B}, {steps} timed steps after 1 warm-up, {dt:.2f} s/step"}
+    return B / dt, dt
+
+
+def _cpu_sample_leg(n, steps):
+    """10 denoise steps of the CPU oracle's sampling loop (Config D), scaled x 99.9 to the 999 of a trajectory
+    (SURVEY 8d): (images/s for a full trajectory, s per denoise step)."""
+    import contextlib, io
+    import afdm
+    from oracle import ref_ops as R
+    afdm.set_seed(42)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device="cpu", variant=3)
+    sd = net.state_dict()
+    beta, alpha, ah = R.noise_schedule(1000)
+    x = torch.randn(n, 3, 32, 32)
+    with torch.no_grad():
+        t0 = None
+        for k, i in enumerate(reversed(range(999 - steps, 1000))):          # 1 warm-up + `steps` timed
+            if k == 1:
+                t0 = time.perf_counter()
+            t = torch.full((n,), i, dtype=torch.long)
+            x = R.denoise_step(beta, alpha, ah, x, R.unet_forward(sd, x, t, 3, F_SET), i, torch.randn_like(x))
+        per = (time.perf_counter() - t0) / steps
+    return n / (per * 999), per
+
+
+def cpu_baseline(variant=3):
+    """The CPU oracle (oracle/ref_ops.py, torch-CPU fp32: the reference's own ATen path restated) on the GPU box's host
+    cores, bounded samples of the same workloads (~25 s of CPU work in all): `value` is the train step of the benched
+    variant at B=64 (instead of 256), `legs` adds BASELINE config 1 (variant 0, 1 channel, B=16) and the sampling loop."""
+    torch.set_num_threads(host_threads())
+    cores = torch.get_num_threads()
+    v, dt = _cpu_train_leg(variant, 3, 64, 3)
+    legs = [{"config": f"variant {variant} train step, 3x32x32, B=64", "value": round(v, 2), "unit": "images/s", "s_per_step": round(dt, 3)}]
+    v1, dt1 = _cpu_train_leg(0, 1, 16, 3)
+    legs.append({"config": "BASELINE config 1: variant 0 (Config A), MNIST-shaped 1x32x32, B=16 train step", "value": round(v1, 2),
+                 "unit": "images/s", "s_per_step": round(dt1, 3)})
+    vs, per = _cpu_sample_leg(16, 10)
+    legs.append({"config": "Config D sample, n=16: 10 timed denoise steps x 99.9 -> one 999-step trajectory", "value": round(vs, 4),
+                 "unit": "images/s", "s_per_denoise_step": round(per, 3)})
+    return {"value": round(v, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle (oracle/ref_ops.py, torch-CPU fp32) train step, variant {variant}, B=64, 3 timed steps after 1 warm-up, {dt:.2f} s/step",
+            "legs": legs}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--variant", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true", help="eager launches only")
@@ -372,7 +411,7 @@ def main():
             result["kernels"] = table
         if not args.no_cpu_baseline:
             log(f"CPU baseline on {host_threads()} host threads")
-            result["cpu_baseline"] = cpu_baseline()
+            result["cpu_baseline"] = cpu_baseline(args.variant)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -208,6 +208,15 @@ int afd_silu_linear_fwd(const float* temb, const float* w, const float* bias, fl
 int afd_silu_linear_bwd(const float* temb, const float* w, const float* dout, float* dw, float* dbias,
                         float* dtemb /* or NULL; accumulated into */, int B, int K, int N, int accumulate, afd_stream_t stream);
 
+/* label conditioning: out[b, :] = temb[b, :] + table[y[b], :]   (nn.Embedding lookup + add, ddpm_models.py:254,276-277)
+ * y: (B,) int64 class indices in [0, num_classes); out may alias temb.
+ * bwd: dtable[k, :] (+)= sum over {b : y[b] == k} of dout[b, :], rows summed in batch order (deterministic, no atomics);
+ * rows of classes absent from y are zeroed (accumulate = 0) or left alone (accumulate = 1). */
+int afd_embed_add_fwd(const float* temb, const float* table, const int64_t* y, float* out, int B, int D, int num_classes,
+                      afd_stream_t stream);
+int afd_embed_add_bwd(const float* dout, const int64_t* y, float* dtable, int B, int D, int num_classes, int accumulate,
+                      afd_stream_t stream);
+
 /* ---- F14/F16: DDPM noise / denoise / quantise ------------------ ddpm_models.py:317-321, 367-374, 381-385
  * Bit-exact restatements of the reference's fp32 expression order (no FMA contraction).
  * t: (B,) int64 indices into the (T,) schedule tables. */

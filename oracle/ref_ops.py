@@ -219,14 +219,17 @@ def up_stage(sd, p, x, skip, temb, variant, filt):
     return emb_add(sd, p, x, temb)
 
 
-def unet_forward(sd, x, t, variant, f_settings=None, time_dim=256):
-    """UNet.forward (ddpm_models.py:271-298) for variants 0..3, unconditional."""
+def unet_forward(sd, x, t, variant, f_settings=None, time_dim=256, y=None):
+    """UNet.forward (ddpm_models.py:271-298) for variants 0..3; `y` (class labels) adds label_emb(y) to the time
+    embedding (:276-277)."""
     filt = None
     if variant:
         filt = (lowpass_kernel(f_settings["omega_c_up"], f_settings["kernel_size"], f_settings["kaiser_beta"]).to(x.dtype),
                 lowpass_kernel(f_settings["omega_c_down"], f_settings["kernel_size"], f_settings["kaiser_beta"]).to(x.dtype))
     f = filt if variant in (2, 3) else None
     temb = time_embedding(t, time_dim).to(x.dtype)
+    if y is not None:
+        temb = temb + sd["label_emb.weight"][y].to(x.dtype)
     x1 = double_conv(sd, "inc.", x, False, f)
     x2 = self_attention(sd, "sa1.", down_stage(sd, "down1.", x1, temb, variant, filt))
     x3 = self_attention(sd, "sa2.", down_stage(sd, "down2.", x2, temb, variant, filt))
@@ -312,10 +315,11 @@ def adamw_step(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.01):
 
 
 def train_step_loss_and_grads(sd, images, t, eps, variant, f_settings, alpha_hat):
-    """ddpm_utils.py:500-506 with t and eps injected.  `sd` tensors must require grad."""
+    """ddpm_utils.py:500-506 with t and eps injected.  `sd` tensors must require grad.  Parameters the forward does
+    not use (label_emb of an unconditional step) get no gradient, as in the reference (grad None -> AdamW skips them)."""
     x_t = noise_images(alpha_hat, images, t, eps)
     pred = unet_forward(sd, x_t, t, variant, f_settings)
     loss = F.mse_loss(eps, pred)
     names = [k for k, v in sd.items() if v.requires_grad]
-    grads = torch.autograd.grad(loss, [sd[k] for k in names])
-    return loss.detach(), pred.detach(), dict(zip(names, grads))
+    grads = torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True)
+    return loss.detach(), pred.detach(), {k: g for k, g in zip(names, grads) if g is not None}

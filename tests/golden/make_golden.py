@@ -254,16 +254,27 @@ def gen_schedule(rm, rutil):
     save("schedule.npz", **out)
 
 
-def gen_train_step(rm, rutil):
-    """One reference train-step body (ddpm_utils.py:498-509) on CPU, B=4, Config D, c=3."""
+TRAIN_KEYS = {     # parameters whose full gradient / post-step value is stored (the rest: checksums); per key scheme
+    True: ("outc.weight", "outc.bias", "inc.conv1.weight", "inc.norm1.weight", "sa3.mha.in_proj_bias", "sa6.ln.weight",
+           "down1.emb_layer.1.bias", "up3.conv.1.conv2.weight", "bot2.norm2.bias", "sa6.mha.out_proj.weight"),
+    False: ("outc.weight", "outc.bias", "inc.double_conv.0.weight", "inc.double_conv.1.weight", "sa3.mha.in_proj_bias",
+            "sa6.ln.weight", "down1.emb_layer.1.bias", "up3.conv.1.double_conv.3.weight", "bot2.double_conv.4.bias",
+            "sa6.mha.out_proj.weight"),
+}
+
+
+def gen_train_step(rm, rutil, variant=3):
+    """Two reference train-step bodies (ddpm_utils.py:498-509) on CPU, B=4, c=3, for one UNet variant.
+    variant 3 -> train_step.npz (Config D); variants 0 / 1 / 2 -> train_step_v{0,1,2}.npz (Configs A / B / C)."""
     out = {}
     rutil.set_seed(42)
-    model = rm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device="cpu", variant=3)
+    model = rm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET) if variant else None, device="cpu", variant=variant)
     diff = rm.Diffusion(noise_steps=1000, img_size=32, device="cpu")
     opt = torch.optim.AdamW(model.parameters(), lr=3e-4)
     mse = torch.nn.MSELoss()
     g = torch.Generator().manual_seed(42)
     images = torch.rand(4, 3, 32, 32, generator=g) * 2 - 1
+    keys = TRAIN_KEYS[variant in (2, 3)]
     losses = []
     for step in range(2):
         t = diff.sample_timesteps(images.shape[0])
@@ -279,22 +290,66 @@ def gen_train_step(rm, rutil):
                 g64 = p.grad.double()
                 gsum.append([g64.sum().item(), g64.abs().sum().item(), g64.pow(2).sum().sqrt().item()])
             out["grad_checksums0"] = np.array(gsum)
-            for kname in ("outc.weight", "outc.bias", "inc.conv1.weight", "inc.norm1.weight",
-                          "sa3.mha.in_proj_bias", "sa6.ln.weight", "down1.emb_layer.1.bias",
-                          "up3.conv.1.conv2.weight", "bot2.norm2.bias", "sa6.mha.out_proj.weight"):
+            for kname in keys:
                 out[f"grad0.{kname}"] = n(dict(model.named_parameters())[kname].grad)
         else:
             out["t1"], out["eps1"] = n(t), n(noise)
         opt.step()
         losses.append(loss.item())
         if step == 0:
-            for kname in ("outc.weight", "outc.bias", "inc.conv1.weight", "sa6.ln.weight",
-                          "up3.conv.1.conv2.weight", "bot2.norm2.bias"):
+            for kname in keys[:3] + (keys[5], keys[7], keys[8]):
                 out[f"param1.{kname}"] = n(dict(model.named_parameters())[kname])
     out["images"] = n(images)
     out["losses"] = np.array(losses, dtype=np.float64)
     out["param_checksums_after2"] = _param_checksums(model)
-    save("train_step.npz", **out)
+    save("train_step.npz" if variant == 3 else f"train_step_v{variant}.npz", **out)
+
+
+def gen_conditional(rm, rutil):
+    """Conditional UNet (num_classes=10, ddpm_models.py:254-258,276-277): forward with labels and the gradient that
+    reaches label_emb; plus the reference AdamW's treatment of parameters that never receive a gradient (variant 4's
+    stage-level norm1, and label_emb when no labels are passed): they keep their initial value."""
+    out = {}
+    rutil.set_seed(42)
+    net = rm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device="cpu", variant=3, num_classes=10)
+    g = torch.Generator().manual_seed(321)
+    x = torch.randn(4, 3, 32, 32, generator=g)
+    t = torch.tensor([500, 37, 999, 1], dtype=torch.long)
+    y = torch.tensor([3, 9, 3, 0], dtype=torch.long)
+    out["x"], out["t"], out["labels"] = n(x), n(t), n(y)
+    out["n_params"] = np.array(sum(p.numel() for p in net.parameters()))
+    out["keys"] = np.array(json.dumps(list(net.state_dict().keys())))
+    out["label_emb"] = n(net.label_emb.weight)
+    pred = net(x, t, y)
+    dy = torch.randn(pred.shape, generator=g)
+    pred.backward(dy)
+    out["y"], out["dy"] = n(pred), n(dy)
+    out["d_label_emb"] = n(net.label_emb.weight.grad)
+    out["d_outc_weight"] = n(net.outc.weight.grad)
+    out["d_down1_emb_weight"] = n(net.down1.emb_layer[1].weight.grad)
+    with torch.no_grad():
+        out["y_uncond"] = n(net(x, t))
+    # variant 4, two AdamW steps without labels: which parameters does the reference leave untouched?
+    rutil.set_seed(42)
+    net4 = rm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device="cpu", variant=4, num_classes=10)
+    before = {k: v.clone() for k, v in net4.state_dict().items()}
+    opt = torch.optim.AdamW(net4.parameters(), lr=3e-4)
+    diff = rm.Diffusion(noise_steps=1000, img_size=32, device="cpu")
+    imgs = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    ts, es, ls = [], [], []
+    for _ in range(2):
+        tt = diff.sample_timesteps(2)
+        x_t, noise = diff.noise_images(imgs, tt)
+        loss = torch.nn.functional.mse_loss(noise, net4(x_t, tt))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ts.append(n(tt)); es.append(n(noise)); ls.append(loss.item())
+    untouched = [k for k, v in net4.state_dict().items() if torch.equal(v, before[k])]
+    out["v4.images"], out["v4.t"], out["v4.eps"], out["v4.losses"] = n(imgs), np.stack(ts), np.stack(es), np.array(ls)
+    out["v4.untouched"] = np.array(json.dumps(untouched))
+    out["v4.param_checksums_after2"] = _param_checksums(net4)
+    save("conditional.npz", **out)
 
 
 def gen_sample(rm, rutil):
@@ -383,7 +438,7 @@ def gen_sample_full(rm, rutil):
 def main():
     torch.set_num_threads(8)
     rf, ru, rm, rutil = _import_reference()
-    which = sys.argv[1:] or ["filters", "resample", "blocks", "unet", "schedule", "train", "sample"]
+    which = sys.argv[1:] or ["filters", "resample", "blocks", "unet", "schedule", "train", "train_variants", "conditional", "sample"]
     if "filters" in which:
         gen_filters(rf)
     if "resample" in which:
@@ -396,6 +451,11 @@ def main():
         gen_schedule(rm, rutil)
     if "train" in which:
         gen_train_step(rm, rutil)
+    for v in (0, 1, 2):
+        if f"train_v{v}" in which or "train_variants" in which:
+            gen_train_step(rm, rutil, v)
+    if "conditional" in which:
+        gen_conditional(rm, rutil)
     if "sample" in which:
         gen_sample(rm, rutil)
     if "sample_full" in which:                  # ~10 minutes of CPU: not part of the default set

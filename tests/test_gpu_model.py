@@ -149,9 +149,9 @@ def test_constructor_errors_and_cpu_forward_fails_loudly(A):
         net(torch.randn(1, 1, 32, 32), torch.tensor([5]))
 
 
-def _train_setup(afdm, dev):
+def _train_setup(afdm, dev, variant=3):
     afdm.set_seed(42)
-    model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device=dev, variant=3).to(dev)
+    model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET) if variant else None, device=dev, variant=variant).to(dev)
     diff = afdm.Diffusion(noise_steps=1000, img_size=32, device=dev)
     return model, diff
 
@@ -169,27 +169,42 @@ def conv_path(A, request):
     L.afd_debug_conv_path(96)
 
 
-@pytest.mark.parametrize("conv_path", ["auto", "winograd", "direct"], indirect=True)
-def test_train_step_vs_reference(A, conv_path):
-    """ddpm_utils.py:499-507 with t / eps injected from the reference's own CPU run (B=4, Config D)."""
+@pytest.mark.parametrize("variant,conv_path", [(3, "auto"), (3, "winograd"), (3, "direct"), (0, "auto"), (1, "auto"), (1, "winograd"),
+                                               (2, "auto")], indirect=["conv_path"])
+def test_train_step_vs_reference(A, variant, conv_path):
+    """ddpm_utils.py:499-507 with t / eps injected from the reference's own CPU run (B=4): Config D (variant 3, under
+    each convolution path) and Configs A / B / C (variants 0 / 1 / 2, Train.ipynb:106 sweeps them)."""
     afdm, dev = A
-    g = load_golden("train_step.npz")
-    model, diff = _train_setup(afdm, dev)
+    g = load_golden("train_step.npz" if variant == 3 else f"train_step_v{variant}.npz")
+    model, diff = _train_setup(afdm, dev, variant)
     names = [n for n, _ in model.named_parameters()]
     step = afdm.TrainStep(model, diff, lr=3e-4, graph=False)
     images = T(g["images"]).to(dev)
     l0 = step(images, t=T(g["t0"]), eps=T(g["eps0"]).to(dev))
-    assert abs(l0.item() - g["losses"][0]) < 2e-5 * abs(g["losses"][0])
+    e_loss0 = abs(l0.item() - g["losses"][0]) / abs(g["losses"][0])
     params = dict(model.named_parameters())
     l2 = np.array([params[n].grad.double().pow(2).sum().sqrt().item() for n in names])
-    assert np.allclose(l2, g["grad_checksums0"][:, 2], rtol=3e-4, atol=1e-8)
-    for key in g.files:
-        if key.startswith("grad0."):
-            assert rel_l2(params[key[6:]].grad.cpu(), g[key]) < 1e-4, key
-        if key.startswith("param1."):
-            assert rel_l2(params[key[7:]].detach().cpu(), g[key]) < 1e-4, key      # SURVEY 8d gate
+    e_norm = float(np.max(np.abs(l2 - g["grad_checksums0"][:, 2]) / (np.abs(g["grad_checksums0"][:, 2]) + 1e-8)))
+    e_grad = max(rel_l2(params[k[6:]].grad.cpu(), g[k]) for k in g.files if k.startswith("grad0."))
+    # post-AdamW parameters.  Adam's first step is -lr * g / (|g| + 1e-8): where |g| is within 100x of eps the update
+    # amplifies a 1e-9 absolute gradient difference into percents (zero-initialised biases with |g| ~ 1e-7: even the CPU
+    # oracle, the same ATen ops in another graph, is 8e-5 off the reference on variant 0's bot2 bias), so the 1e-4 gate
+    # is taken over the elements with |g_ref| >= 1e-6 and the whole tensor is gated at 2e-3.
+    e_par, e_par_all = 0.0, 0.0
+    for k in g.files:
+        if k.startswith("param1."):
+            got, want, gref = params[k[7:]].detach().cpu().numpy(), g[k], np.abs(g["grad0." + k[7:]])
+            m = gref >= 1e-6
+            assert m.mean() > 0.9, k
+            e_par = max(e_par, rel_l2(got[m], want[m]))
+            e_par_all = max(e_par_all, rel_l2(got, want))
     l1 = step(images, t=T(g["t1"]), eps=T(g["eps1"]).to(dev))
-    assert abs(l1.item() - g["losses"][1]) < 1e-4 * abs(g["losses"][1])
+    e_loss1 = abs(l1.item() - g["losses"][1]) / abs(g["losses"][1])
+    print(f"train step v{variant} [{conv_path}]: loss0 rel {e_loss0:.2e}, worst grad rel-L2 {e_grad:.2e}, worst grad-norm rel {e_norm:.2e}, "
+          f"worst post-AdamW param rel-L2 {e_par:.2e} (all elements {e_par_all:.2e}), loss1 rel {e_loss1:.2e}")
+    assert e_loss0 < 2e-5 and e_loss1 < 1e-4
+    assert np.allclose(l2, g["grad_checksums0"][:, 2], rtol=3e-4, atol=1e-8)
+    assert e_grad < 1e-4 and e_par < 1e-4 and e_par_all < 2e-3                      # SURVEY 8d gates
     cs = np.array([[v.double().sum().item(), v.double().abs().sum().item()] for v in model.state_dict().values()])
     assert np.allclose(cs[:, 1], g["param_checksums_after2"][:, 1], rtol=1e-3, atol=0.1)   # |.|-sums incl. zero-init biases after 2 Adam steps
 
@@ -222,17 +237,59 @@ def test_graph_replay_equals_eager(A):
     outs = []
     for use_graph in (False, True):
         model, diff = _train_setup(afdm, dev)
-        step = afdm.TrainStep(model, diff, lr=3e-4, graph=use_graph)
-        if use_graph:            # capture warms up with 3 real steps; rewind the state so both runs see the same 2 steps
-            sd0 = {k: v.clone() for k, v in model.state_dict().items()}
-            step(images, t=t0, eps=e0)
-            model.load_state_dict(sd0)
-            step.opt.m.zero_(); step.opt.v.zero_(); step.opt.state.zero_()
-        la = step(images, t=t0, eps=e0).item()
+        step = afdm.TrainStep(model, diff, lr=3e-4, graph=use_graph)      # the capture warm-up must leave no trace: the
+        la = step(images, t=t0, eps=e0).item()                            # first graph call is exactly one step
         lb = step(images, t=t1, eps=e1).item()
         outs.append((la, lb, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()))
+    print("graph vs eager after 2 steps: loss diffs", abs(outs[0][0] - outs[1][0]), abs(outs[0][1] - outs[1][1]),
+          "param rel-L2", rel_l2(outs[1][2], outs[0][2]))
     assert abs(outs[0][0] - outs[1][0]) < 1e-6 and abs(outs[0][1] - outs[1][1]) < 1e-5
     assert rel_l2(outs[1][2], outs[0][2]) < 1e-6
+    with pytest.raises(ValueError, match="injected noise"):
+        step(images, t=t0)                                                # captured with eps: omitting it later is an error
+
+
+def test_unused_parameters_stay_untouched_like_the_reference(A):
+    """Variant 4 (+ num_classes, no labels passed): the reference's AdamW never touches the stage-level norm1 nor
+    label_emb (their grad is None); two steps with the reference's t / eps, then the same per-tensor checksums."""
+    afdm, dev = A
+    g = load_golden("conditional.npz")
+    afdm.set_seed(42)
+    model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device=dev, variant=4, num_classes=10).to(dev)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    diff = afdm.Diffusion(noise_steps=1000, img_size=32, device=dev)
+    step = afdm.TrainStep(model, diff, lr=3e-4, graph=False)
+    images = T(g["v4.images"]).to(dev)
+    for i in range(2):
+        loss = step(images, t=T(g["v4.t"][i]), eps=T(g["v4.eps"][i]).to(dev))
+        assert abs(loss.item() - g["v4.losses"][i]) < 1e-4 * abs(g["v4.losses"][i])
+    untouched = [k for k, v in model.state_dict().items() if torch.equal(v, before[k])]
+    assert untouched == golden_json(g, "v4.untouched")
+    cs = np.array([[v.double().sum().item(), v.double().abs().sum().item()] for v in model.state_dict().values()])
+    assert np.allclose(cs[:, 1], g["v4.param_checksums_after2"][:, 1], rtol=1e-3, atol=0.1)
+
+
+def test_conditional_unet_forward_backward_vs_reference(A):
+    """UNet(num_classes=10).forward(x, t, y) (ddpm_models.py:254-258,276-277): the label embedding goes through the C ABI
+    (afd_embed_add_*); forward, the gradient reaching label_emb and two other parameters vs the reference."""
+    afdm, dev = A
+    g = load_golden("conditional.npz")
+    afdm.set_seed(42)
+    net = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device=dev, variant=3, num_classes=10)
+    assert list(net.state_dict().keys()) == golden_json(g, "keys")
+    net = net.to(dev)
+    x, t, y = T(g["x"]).to(dev), T(g["t"]).to(dev), T(g["labels"]).to(dev)
+    pred = net(x, t, y)
+    e_f = rel_l2(pred.detach().cpu(), g["y"])
+    dl, dw, de = torch.autograd.grad(pred, [net.label_emb.weight, net.outc.weight, net.down1.emb_layer[1].weight], T(g["dy"]).to(dev))
+    errs = (rel_l2(dl.cpu(), g["d_label_emb"]), rel_l2(dw.cpu(), g["d_outc_weight"]), rel_l2(de.cpu(), g["d_down1_emb_weight"]))
+    print(f"conditional UNet: fwd rel-L2 {e_f:.2e}; d label_emb / outc.weight / down1.emb weight rel-L2 {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
+    assert e_f < 1e-5 and max(errs) < 1e-4
+    assert float(dl[1].abs().max()) == 0.0                              # class 1 is absent from y
+    with torch.no_grad():
+        assert rel_l2(net(x, t).cpu(), g["y_uncond"]) < 1e-5 and rel_l2(net(x, t, y).cpu(), g["y"]) < 1e-5
+    with pytest.raises(RuntimeError, match="int64"):
+        net(x, t, y.float())
 
 
 @pytest.mark.parametrize("conv_path", ["auto", "winograd"], indirect=True)
@@ -337,13 +394,42 @@ def test_graph_sampling_equals_eager_sampling(A):
         afdm.set_seed(5)
         xq, rq, xf = diff.sample(model, n=3, image_channels=3, noise_source="device", return_float=True, graph=use_graph)
         outs.append((xq.cpu(), rq.cpu(), xf.cpu()))
-    # the eager loop draws its noise with the same generator calls in the same order, but the capture warm-up
-    # consumes one extra draw: compare distributions instead of bits when the streams differ
-    same_stream = torch.equal(outs[0][2], outs[1][2])
-    if not same_stream:
-        assert outs[0][2].shape == outs[1][2].shape and torch.isfinite(outs[1][2]).all()
-        assert abs(outs[0][2].std().item() - outs[1][2].std().item()) < 0.2 * outs[0][2].std().item()
-    assert outs[1][1].shape == outs[0][1].shape
+    # the capture warm-up's effects (x, the device generator's state) are undone, so the replays draw the very noise the
+    # eager loop draws: same images bit for bit
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_sample_concurrent_cold_cache_winograd_unequal_batches(A):
+    """Trajectories on several streams, every 3x3 layer on the Winograd kernels (cached transformed weights), starting
+    from a COLD cache (as after any optimiser step) with unequal batch sizes: each stream must fill and read its own
+    transformed-weight images and timestep tables; the result equals the one-stream run bit for bit."""
+    afdm, dev = A
+    from afdm import ops
+    L = afdm.lib()
+    afdm.set_seed(42)
+    model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device=dev, variant=3).to(dev)
+    diff = afdm.Diffusion(noise_steps=9, img_size=32, device=dev)
+
+    def noise_fn(k, i, shape):
+        g = torch.Generator().manual_seed(77 * k + i)
+        return torch.randn(shape, generator=g).to(dev)
+
+    for m in (67, 98):
+        L.afd_debug_conv_path(m)                        # force Winograd (the by-rule choice keeps small batches direct)
+    try:
+        outs = []
+        for streams in (3, 1, 3):
+            ops.bump_param_epoch()                      # cold cache: every cached transform is stale
+            diff._t_cache.clear()
+            outs.append(diff.sample_concurrent(model, n=37, image_channels=3, batch=16, streams=streams, noise_fn=noise_fn))
+            torch.cuda.synchronize()
+    finally:
+        L.afd_debug_conv_path(64)
+        L.afd_debug_conv_path(96)
+    assert outs[0][0].shape == (37, 3, 32, 32)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[2][0], outs[1][0]) and torch.equal(outs[2][1], outs[1][1])
+    assert len({k[2] for k in ops._WinoWeights.store}) >= 3           # one set of images per stream
 
 
 def test_graph_step_matches_eager_step_bitwise(A):
@@ -392,23 +478,79 @@ def test_ddpm_run_drop_in_end_to_end(A, tmp_path, monkeypatch):
     assert len(sd) == 182        # reference checkpoint wire format: same 182 keys
 
 
-def test_two_rank_data_parallel_equals_single_rank(A, tmp_path):
-    """2 processes on the one GPU (gloo, host-staged all-reduce): B=2+2 must equal one rank with B=4."""
-    import os
+def _run_ranks(tmp_path, mode, port, name, backend="gloo", extra_env=None):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = tmp_path / "ddp.pt"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", PYTHONPATH=root)
+    out = tmp_path / name
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               **(extra_env or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "tests", "ddp_worker.py"), "--device", "cuda", "--out", str(out)]
-    subprocess.run(cmd, check=True, env=env, timeout=600)
-    got = torch.load(out, weights_only=True)
-    afdm, dev = A
+           "--master-port", str(port), os.path.join(root, "tests", "ddp_worker.py"), "--device", "cuda", "--mode", mode,
+           "--backend", backend, "--out", str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=900)
+    return torch.load(out, weights_only=True)
+
+
+def _single_rank_step(afdm, dev):
     g = load_golden("train_step.npz")
     model, diff = _train_setup(afdm, dev)
     step = afdm.TrainStep(model, diff, lr=3e-4, graph=False)
     loss = step(T(g["images"]).to(dev), t=T(g["t0"]), eps=T(g["eps0"]).to(dev)).item()
-    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+    return loss, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+
+
+def test_two_rank_data_parallel_equals_single_rank(A, tmp_path):
+    """2 processes on the one GPU (gloo, buckets staged through the host): B=2+2 must equal one rank with B=4, and the
+    bucket all-reduces must have started DURING backward (all but the first-layers bucket, which completes with it)."""
+    afdm, dev = A
+    got = _run_ranks(tmp_path, "train", 29533, "ddp.pt")
+    loss, flat = _single_rank_step(afdm, dev)
+    print("2-rank vs 1-rank: loss rel", abs(got["loss_mean"] - loss) / abs(loss), "param rel-L2", rel_l2(got["params"], flat),
+          "buckets", got["slices"].tolist(), "started before the end of backward:", got["overlapped_buckets"])
     assert abs(got["loss_mean"] - loss) < 1e-5 * abs(loss)
     assert rel_l2(got["params"], flat) < 1e-6
+    assert got["n_buckets"] == 4 and got["overlapped_buckets"] == 4
+
+
+def test_two_rank_data_parallel_graph_mode(A, tmp_path):
+    """TrainStep(graph=True, distributed=True): the captured forward + backward, then the whole exchange + AdamW."""
+    afdm, dev = A
+    got = _run_ranks(tmp_path, "train", 29534, "ddp_graph.pt", extra_env={"AFD_TEST_GRAPH": "1"})
+    loss, flat = _single_rank_step(afdm, dev)
+    assert abs(got["loss_mean"] - loss) < 1e-5 * abs(loss) and rel_l2(got["params"], flat) < 1e-6
+    assert got["overlapped_buckets"] == 0
+
+
+def test_two_rank_rccl_data_parallel(A, tmp_path):
+    """The 'nccl' (= RCCL) branch: one rank per GPU, bucket all-reduces on the collective stream behind events.
+    Needs two GPUs: skipped on the one-GPU test box."""
+    afdm, dev = A
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL path; unmeasured on hardware so far)")
+    got = _run_ranks(tmp_path, "train", 29535, "ddp_rccl.pt", backend="nccl")
+    loss, flat = _single_rank_step(afdm, dev)
+    assert abs(got["loss_mean"] - loss) < 1e-5 * abs(loss) and rel_l2(got["params"], flat) < 1e-6
+    assert got["overlapped_buckets"] == 4
+
+
+def test_two_rank_sharded_sampling_equals_single_rank(A, tmp_path):
+    """Diffusion.sample_sharded / sample_rotation_sweep_sharded over 2 ranks (n = 5 -> shards of 2 and 3 images; 3 angles
+    -> 1 and 2): gathered on rank 0, bit-identical to the one-rank calls under the same seed (ddpm_tasks.py:346-369, :365)."""
+    afdm, dev = A
+    got = _run_ranks(tmp_path, "sample", 29536, "sample.pt")
+    afdm.set_seed(42)
+    model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device=dev, variant=3).to(dev)
+    diff = afdm.Diffusion(noise_steps=201, img_size=32, device=dev)
+    afdm.set_seed(5)
+    xq, rq = diff.sample(model, n=5, image_channels=3)
+    assert got["x"].shape == (5, 3, 32, 32) and got["result"].shape == (15, 3, 32, 32)
+    assert torch.equal(got["x"], xq.cpu()) and torch.equal(got["result"], rq.cpu())
+    afdm.set_seed(5)
+    xs, rs = diff.sample_rotation_sweep(model, 2, 3, [-90.0, 0.0, 45.0])
+    assert torch.equal(got["rot_x"], torch.stack([t.cpu() for t in xs]))
+    assert torch.equal(got["rot_result"], torch.stack([t.cpu() for t in rs]))
+    # and the unsharded entry points are what the sharded ones fall back to without a process group
+    afdm.set_seed(5)
+    x1, r1 = diff.sample_sharded(model, n=5, image_channels=3)
+    assert torch.equal(x1, xq) and torch.equal(r1, rq)

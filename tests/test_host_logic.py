@@ -105,6 +105,44 @@ def test_modules_shim_resolves_reference_import_paths():
     assert UNet is afdm.UNet and Diffusion is afdm.Diffusion
 
 
+def test_stage_classes_are_real_module_subclasses():
+    """ddpm_utils.py:199-480 define Down / Up / *_F / *_FF / *_FFF as nn.Module classes: isinstance and subclassing work."""
+    import afdm
+    fs = dict(F_SET)
+    d, u = afdm.Down_FFF(4, 8, f_settings=fs), afdm.Up_FF(8, 4, f_settings=fs)
+    assert isinstance(d, afdm.Down_FFF) and isinstance(d, torch.nn.Module) and not isinstance(d, afdm.Down_FF)
+    assert isinstance(u, afdm.Up_FF) and not isinstance(u, afdm.Up_FFF)
+    assert isinstance(afdm.Down(4, 8), afdm.Down) and isinstance(afdm.Up(8, 4), afdm.Up)
+
+    class MyDown(afdm.Down_F):
+        pass
+    assert isinstance(MyDown(4, 8, f_settings=fs), afdm.Down_F)
+    with pytest.raises(ValueError, match="f_settings is empty"):
+        afdm.Down_F(4, 8)
+    net = afdm.UNet(c_in=1, c_out=1, image_size=32, f_settings=fs, device="cpu", variant=3)
+    assert isinstance(net.down1, afdm.Down_FFF) and isinstance(net.up3, afdm.Up_FFF) and isinstance(net.inc, afdm.DoubleConv_F)
+
+
+def test_flat_params_keep_unused_parameters_out_of_the_optimiser_range():
+    """The reference's AdamW skips parameters whose grad is None (variant 4's stage-level norm1, label_emb without labels):
+    FlatParams puts them behind n_active, where the fused AdamW launch never reaches."""
+    import afdm
+    afdm.set_seed(0)
+    net = afdm.UNet(c_in=1, c_out=1, image_size=32, f_settings=dict(F_SET), device="cpu", variant=4, num_classes=5)
+    unused = net.unused_parameters()
+    n_unused = sum(p.numel() for p in unused)
+    assert n_unused == 2 * (32 + 64 + 128 + 128 + 64 + 32) + 5 * 256
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    fp = afdm.FlatParams(net)
+    assert fp.n_active == fp.numel - n_unused
+    tail = {id(p) for p in fp.params[len(fp.params) - len(unused):]}
+    assert tail == {id(p) for p in unused}
+    assert all(p.data_ptr() == fp.flat.data_ptr() + 4 * o for p, o in zip(fp.params, fp.offsets))
+    assert all(o + p.numel() <= fp.n_active for p, o in zip(fp.params, fp.offsets) if id(p) not in tail)
+    assert all(torch.equal(v, sd0[k]) for k, v in net.state_dict().items())       # re-homing moved storage, not values
+    assert afdm.FlatParams(torch.nn.Linear(3, 2)).n_active == 8                    # models without the hook: everything active
+
+
 def _write_mnist_csv(path, n=24):
     rng = np.random.default_rng(0)
     arr = np.concatenate([rng.integers(0, 10, (n, 1)), rng.integers(0, 256, (n, 784))], axis=1)
@@ -135,11 +173,36 @@ def test_loaders_without_torchvision(tmp_path):
     assert (out / "image_3.png").exists() and os.path.exists(str(out) + "_collage_0.png")
 
 
-def test_two_rank_gloo_gradient_exchange(tmp_path):
-    out = tmp_path / "ddp_cpu.pt"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", PYTHONPATH=ROOT, OMP_NUM_THREADS="2")
+def _run_workers(tmp_path, mode, port, name):
+    out = tmp_path / name
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=ROOT, OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", os.path.join(ROOT, "tests", "ddp_worker.py"), "--device", "cpu", "--out", str(out)]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "ddp_worker.py"), "--device", "cpu", "--mode", mode,
+           "--out", str(out)]
     subprocess.run(cmd, check=True, env=env, timeout=300)
-    res = torch.load(out, weights_only=True)
+    return torch.load(out, weights_only=True)
+
+
+def test_two_rank_gloo_gradient_exchange(tmp_path):
+    """world_size 2: module-boundary buckets, readiness bookkeeping (a bucket's all-reduce starts when its last
+    gradient is reported, i.e. during backward), the everything-at-the-end form, and the mean."""
+    res = _run_workers(tmp_path, "grads", 29531, "ddp_cpu.pt")
     assert res["ok"] and res["world"] == 2
+
+
+def test_two_rank_gloo_shard_and_gather(tmp_path):
+    """world_size 2: the partition / gather-on-rank-0 helpers of the sharded sampling paths (uneven and empty shards)."""
+    res = _run_workers(tmp_path, "shards", 29532, "shards_cpu.pt")
+    assert res["ok"] and res["world"] == 2
+
+
+def test_unet_gradient_buckets_follow_the_layer_order():
+    """Config D: 4 buckets cut at top-level module boundaries from the output end; the bucket that becomes ready last
+    (inc .. sa2) is the smallest."""
+    import afdm
+    afdm.set_seed(0)
+    net = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device="cpu", variant=3)
+    fp = afdm.FlatParams(net)
+    ddp = afdm.GradAllReduce(fp, n_buckets=4, model=net)
+    assert ddp.slices == [(0, 554144), (554144, 2163232), (2163232, 3786784), (3786784, 5897155)]
+    assert sum(ddp._count) == len(fp.params) and ddp.world == 1 and ddp.finish() == 1.0

@@ -133,12 +133,14 @@ def test_schedule_bit_exact():
     assert list(g["t_seed42_n8"]) == [790, 618, 251, 50, 64, 435, 413, 942]
 
 
-def test_train_step_loss_and_grads():
-    g = load_golden("train_step.npz")
-    net = _init_like_reference(3, 3)
+@pytest.mark.parametrize("variant", [3, 0, 1, 2])
+def test_train_step_loss_and_grads(variant):
+    """Configs D / A / B / C: the oracle's train step against the reference's own (B=4, its t / eps)."""
+    g = load_golden("train_step.npz" if variant == 3 else f"train_step_v{variant}.npz")
+    net = _init_like_reference(variant, 3)
     sd = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
     _, _, ah = R.noise_schedule(1000)
-    loss, pred, grads = R.train_step_loss_and_grads(sd, T(g["images"]), T(g["t0"]), T(g["eps0"]), 3, F_SET, ah)
+    loss, pred, grads = R.train_step_loss_and_grads(sd, T(g["images"]), T(g["t0"]), T(g["eps0"]), variant, F_SET, ah)
     assert abs(loss.item() - g["losses"][0]) < 1e-5 * abs(g["losses"][0])
     assert rel_l2(pred, g["pred0"]) < 5e-6
     for key in g.files:
@@ -154,6 +156,30 @@ def test_train_step_loss_and_grads():
             p1, _, _ = R.adamw_step(sd[n].detach(), T(g["grad0." + n]) if "grad0." + n in g.files else grads[n],
                                     torch.zeros_like(sd[n]), torch.zeros_like(sd[n]), 1, 3e-4)
             assert rel_l2(p1, g[key]) < 1e-6, key
+
+
+def test_conditional_forward_and_label_embedding_gradient():
+    """ddpm_models.py:254-258,276-277: t_emb += label_emb(y)."""
+    import afdm
+    g = load_golden("conditional.npz")
+    afdm.set_seed(42)
+    net = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device="cpu", variant=3, num_classes=10)
+    assert list(net.state_dict().keys()) == golden_json(g, "keys") and sum(p.numel() for p in net.parameters()) == int(g["n_params"])
+    assert np.array_equal(net.label_emb.weight.detach().numpy(), g["label_emb"])          # seeded init incl. the embedding
+    sd = {k: v.clone().requires_grad_(k in ("label_emb.weight", "outc.weight")) for k, v in net.state_dict().items()}
+    x, t, y = T(g["x"]), T(g["t"]), T(g["labels"])
+    pred = R.unet_forward(sd, x, t, 3, F_SET, y=y)
+    assert rel_l2(pred.detach(), g["y"]) < 5e-6
+    dl, dw = torch.autograd.grad(pred, [sd["label_emb.weight"], sd["outc.weight"]], T(g["dy"]))
+    assert rel_l2(dl, g["d_label_emb"]) < 1e-4 and rel_l2(dw, g["d_outc_weight"]) < 1e-4
+    assert float(dl[1].abs().max()) == 0.0                  # a class absent from y gets no gradient
+    with torch.no_grad():
+        assert rel_l2(R.unet_forward(sd, x, t, 3, F_SET), g["y_uncond"]) < 5e-6
+    # the parameters the reference's optimiser never touches are exactly the ones the shell reports as unused
+    afdm.set_seed(42)
+    net4 = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device="cpu", variant=4, num_classes=10)
+    ids = {id(p) for p in net4.unused_parameters()}
+    assert [k for k, p in net4.named_parameters() if id(p) in ids] == golden_json(g, "v4.untouched")
 
 
 def test_sample_loop_quantised_and_float():
