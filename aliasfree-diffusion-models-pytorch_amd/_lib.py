@@ -42,6 +42,9 @@ def parse_header(path=HEADER):
     return out
 
 
+_VALUE_RETURNING = {"afd_device_count", "afd_tok_supported"}      # int results, not status codes
+
+
 class AfdError(RuntimeError):
     pass
 
@@ -57,7 +60,7 @@ class _Lib:
         for name, (restype, argtypes) in self.sigs.items():
             fn = getattr(self.cdll, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = restype, argtypes
-            if restype is ctypes.c_int and name != "afd_device_count":
+            if restype is ctypes.c_int and name not in _VALUE_RETURNING:
                 setattr(self, name, self._checked(name, fn))
             else:
                 setattr(self, name, fn)

@@ -30,6 +30,7 @@ class SelfAttention(nn.Module):
     tokens are pixels, so every projection is a 1x1 convolution and no transpose ever runs."""
 
     heads = 4
+    fused = True          # the token-wise chains as two fused launches (csrc/tok.hip) where the width is covered
 
     def __init__(self, channels, size):
         super().__init__()
@@ -42,6 +43,12 @@ class SelfAttention(nn.Module):
     def forward(self, x):
         C = self.channels
         x = x.reshape(-1, C, self.size, self.size)
+        if self.fused and ops.tok_supported(C):
+            m, ff = self.mha, self.ff_self
+            qkv, x_res = ops.AttnHead.apply(x, self.ln.weight, self.ln.bias, m.in_proj_weight, m.in_proj_bias)
+            att = ops.Attention.apply(qkv, self.heads)
+            return ops.AttnTail.apply(att, x_res, m.out_proj.weight, m.out_proj.bias, ff[0].weight, ff[0].bias,
+                                      ff[1].weight, ff[1].bias, ff[3].weight, ff[3].bias)
         as1x1 = lambda w: w.reshape(w.shape[0], w.shape[1], 1, 1)
         h, x_res = ops.LayerNormC.apply(x, self.ln.weight, self.ln.bias)         # x_res: x for the residual, via the LN node
         lin = lambda z, w, b, res=None: ops.conv(z, as1x1(w), b, res=res, w_param=w, b_param=b)

@@ -622,6 +622,122 @@ class Attention(_Fn):
         return dqkv, None
 
 
+def tok_supported(C):
+    """True if the fused token-chain kernels (csrc/tok.hip) cover channel width C."""
+    return bool(lib().afd_tok_supported(int(C)))
+
+
+def _linear_grads(x, dy, w, b, B, C_in, C_out, H, W, need_w=True):
+    """Weight / bias gradients of a token-wise Linear (= 1x1 convolution) y = w x + b from its input x (B,C_in,H,W) and
+    dy (B,C_out,H,W).  In-place mode: accumulated straight into w.grad / b.grad, on the side stream when there is one
+    (returns (None, None)); otherwise returns fresh (dw, db) for autograd."""
+    L = lib()
+    nbytes = L.afd_conv_wgrad_workspace_bytes(B, C_in, C_out, H, W, 1)
+    ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    if _direct(w, b):
+        dwp, dbp = _p(w.grad), (_p(b.grad) if b is not None else None)
+        fn = lambda st, x=x, dy=dy, ws=ws: L.afd_conv_wgrad(_p(x), _p(dy), dwp, dbp, B, C_in, C_out, H, W, 1, 1, _p(ws), st)
+        if _GradMode.side is not None:
+            defer_to_side_stream(fn, x, dy, ws, writes=(w, b))
+        else:
+            fn(_stream())
+            _wrote(w, b)
+        return None, None
+    dw = torch.empty_like(w)
+    db = torch.empty(C_out, device=x.device, dtype=torch.float32) if b is not None else None
+    L.afd_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), B, C_in, C_out, H, W, 1, 0, _p(ws), _stream())
+    return dw, db
+
+
+def _ln_param_grads(x, dy, stats, gamma, beta, B, C, HW):
+    """LayerNorm-over-channels parameter gradients from the LayerNorm input x, the gradient at its output dy and the
+    saved statistics; same in-place / side-stream convention as _linear_grads."""
+    L = lib()
+    part = torch.empty(B, 2, C, device=x.device, dtype=torch.float32)
+    dg, db, acc, (dgamma, dbeta) = _gn_param_targets(C, gamma, beta, x.device)
+    pdg, pdb = _p(dg), _p(db)
+    fn = lambda st, x=x, dy=dy, stats=stats, part=part: L.afd_layernorm_c_bwd_params(
+        _p(x), _p(dy), _p(stats), B, C, HW, _p(part), pdg, pdb, acc, st)
+    if acc and _GradMode.side is not None:
+        defer_to_side_stream(fn, x, dy, stats, part, writes=(gamma, beta))
+    else:
+        fn(_stream())
+        if acc:
+            _wrote(gamma, beta)
+    return dgamma, dbeta
+
+
+class AttnHead(_Fn):
+    """qkv = in_proj(LayerNorm(x)) in ONE launch (ddpm_utils.py:70-71, csrc/tok.hip); also returns x again for the residual
+    branch, so backward receives both gradients of x and the fused backward kernel adds them."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w_in, b_in):
+        _chk(x, gamma, beta, w_in, b_in)
+        x = _c(x)
+        B, C, H, W = x.shape
+        train = not isinstance(ctx, _NoCtx)             # (forward itself always runs with grad mode off)
+        qkv = torch.empty(B, 3 * C, H, W, device=x.device, dtype=torch.float32)
+        h = torch.empty_like(x) if train else None
+        stats = torch.empty(B, H * W, 2, device=x.device, dtype=torch.float32) if train else None
+        lib().afd_tok_head_fwd(_p(x), _p(gamma), _p(beta), _p(w_in), _p(b_in), _p(h), _p(stats), _p(qkv), B, C, H * W, LN_EPS, _stream())
+        ctx.save_for_backward(x, h, stats, gamma, w_in)
+        ctx.params = (beta, b_in)
+        return qkv, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dqkv, dres):
+        x, h, stats, gamma, w_in = ctx.saved_tensors
+        beta, b_in = ctx.params
+        B, C, H, W = x.shape
+        dqkv = _c(dqkv)
+        if dres is None:
+            dres = torch.zeros_like(x)
+        dres = _c(dres)
+        dx = torch.empty_like(x)
+        dh = torch.empty_like(x)
+        lib().afd_tok_head_bwd(_p(dqkv), _p(x), _p(stats), _p(gamma), _p(w_in), _p(dres), _p(dh), _p(dx), B, C, H * W, _stream())
+        dw, db = _linear_grads(h, dqkv, w_in, b_in, B, C, 3 * C, H, W)
+        dgamma, dbeta = _ln_param_grads(x, dh, stats, gamma, beta, B, C, H * W)
+        return dx, dgamma, dbeta, dw, db
+
+
+class AttnTail(_Fn):
+    """out = FF(LayerNorm(a)) + a with a = out_proj(att) + x, in ONE launch (ddpm_utils.py:71-73, csrc/tok.hip)."""
+
+    @staticmethod
+    def forward(ctx, att, x, wo, bo, gamma, beta, w1, b1, w2, b2):
+        _chk(att, x, wo, bo, gamma, beta, w1, b1, w2, b2)
+        att, x = _c(att), _c(x)
+        B, C, H, W = att.shape
+        out = torch.empty_like(att)
+        if not isinstance(ctx, _NoCtx):
+            a, f, u, g = (torch.empty_like(att) for _ in range(4))
+            stats = torch.empty(B, H * W, 2, device=att.device, dtype=torch.float32)
+        else:
+            a = f = u = g = stats = None
+        lib().afd_tok_tail_fwd(_p(att), _p(x), _p(wo), _p(bo), _p(gamma), _p(beta), _p(w1), _p(b1), _p(w2), _p(b2),
+                               _p(a), _p(stats), _p(f), _p(u), _p(g), _p(out), B, C, H * W, LN_EPS, _stream())
+        ctx.save_for_backward(att, a, stats, f, u, g, gamma, wo, w1, w2)
+        ctx.params = (bo, beta, b1, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        att, a, stats, f, u, g, gamma, wo, w1, w2 = ctx.saved_tensors
+        bo, beta, b1, b2 = ctx.params
+        B, C, H, W = att.shape
+        dout = _c(dout)
+        du, df, da, datt = (torch.empty_like(att) for _ in range(4))
+        lib().afd_tok_tail_bwd(_p(dout), _p(u), _p(a), _p(stats), _p(gamma), _p(w2), _p(w1), _p(wo),
+                               _p(du), _p(df), _p(da), _p(datt), B, C, H * W, _stream())
+        dw2, db2 = _linear_grads(g, dout, w2, b2, B, C, C, H, W)
+        dw1, db1 = _linear_grads(f, du, w1, b1, B, C, C, H, W)
+        dwo, dbo = _linear_grads(att, da, wo, bo, B, C, C, H, W)
+        dgamma, dbeta = _ln_param_grads(a, df, stats, gamma, beta, B, C, H * W)
+        return datt, da, dwo, dbo, dgamma, dbeta, dw1, db1, dw2, db2
+
+
 class Gelu(_Fn):
     @staticmethod
     def forward(ctx, x):

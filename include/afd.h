@@ -184,6 +184,34 @@ int afd_attn_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d
 int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                  float* delta_workspace /* (B,heads,L) floats */, int B, int heads, int d, int L, afd_stream_t stream);
 
+/* ---- F10: the token-wise chains of SelfAttention fused around the core ------------------- ddpm_utils.py:68-74
+ * Tokens are the pixels of the NCHW tensor (P = H*W per image), every nn.Linear is a 1x1 convolution with its (out,in)
+ * weight, so the block is   x -> [head] -> qkv -> afd_attn_fwd -> att -> [tail] -> out   with
+ *   head: h = LayerNorm(x; gamma, beta) (:70);  qkv = w_in h + b_in  (the MHA in-projection, :71);
+ *   tail: a = w_o att + b_o + x (:71-72);  f = LayerNorm(a) ;  u = w_1 f + b_1;  g = GELU(u);  out = w_2 g + b_2 + a  (:73).
+ * Covered: C in {32, 64, 128} (afd_tok_supported); other widths use the unfused entry points above.
+ * head_fwd: h_out / stats_out (B,P,2 = {mean, rstd}) may be NULL (inference).
+ * tail_fwd: a_out, stats_out, f_out, u_out, g_out are the tensors backward needs -- all five or none (NULL = inference).
+ * tail_bwd: du = (w_2^T d_out) * GELU'(u);  df = w_1^T du;  d_a = LayerNorm'(df; a) + d_out;  d_att = w_o^T d_a.
+ *           du / df / d_a are also what the weight-gradient kernels and afd_layernorm_c_bwd_params consume
+ *           (dW_2 from (g, d_out), dW_1 from (f, du), dW_o from (att, d_a), LayerNorm parameters from (a, df)).
+ * head_bwd: dh = w_in^T dqkv;  dx = LayerNorm'(dh; x) + d_res   (d_res = d_a of the tail: the residual branch);
+ *           dh_out (or NULL) for the LayerNorm parameter gradients. */
+int afd_tok_supported(int C);
+/* test hook: cap the workgroups per launch of the four kernels below (forces several passes per workgroup); 0 = default */
+int afd_debug_tok_grid(int max_workgroups);
+int afd_tok_head_fwd(const float* x, const float* gamma, const float* beta, const float* w_in, const float* b_in,
+                     float* h_out, float* stats_out, float* qkv, int B, int C, int P, float eps, afd_stream_t stream);
+int afd_tok_tail_fwd(const float* att, const float* x, const float* w_o, const float* b_o, const float* gamma, const float* beta,
+                     const float* w_1, const float* b_1, const float* w_2, const float* b_2,
+                     float* a_out, float* stats_out, float* f_out, float* u_out, float* g_out, float* out,
+                     int B, int C, int P, float eps, afd_stream_t stream);
+int afd_tok_tail_bwd(const float* d_out, const float* u, const float* a, const float* stats, const float* gamma,
+                     const float* w_2, const float* w_1, const float* w_o,
+                     float* du_out, float* df_out, float* da_out, float* datt_out, int B, int C, int P, afd_stream_t stream);
+int afd_tok_head_bwd(const float* dqkv, const float* x, const float* stats, const float* gamma, const float* w_in,
+                     const float* d_res, float* dh_out, float* dx_out, int B, int C, int P, afd_stream_t stream);
+
 /* ---- elementwise / pooling used by variants 0 and 2 --------------------------------------------
  * gelu: nn.GELU (ddpm_utils.py:64); maxpool: nn.MaxPool2d(2) (:203,258);
  * bilinear: nn.Upsample(scale_factor=2, 'bilinear', align_corners=True) (:226,280). */

@@ -411,6 +411,90 @@ def test_attention_core(A, cfg, fused):
     assert rel_l2(gd.cpu(), go) < 2e-5
 
 
+TOK_CASES = [(2, 32, 32), (3, 32, 16), (3, 64, 16), (2, 64, 8), (3, 128, 8), (5, 128, 4), (7, 32, 4)]
+
+
+@pytest.mark.parametrize("grid_cap", [0, 1])
+@pytest.mark.parametrize("case", TOK_CASES, ids=[f"B{c[0]}_C{c[1]}_{c[2]}x{c[2]}" for c in TOK_CASES])
+def test_fused_attention_block_vs_oracle_and_unfused(A, case, grid_cap):
+    """SelfAttention (ddpm_utils.py:54-74) through the fused token-chain kernels (csrc/tok.hip: LN + in_proj; out_proj +
+    residual + LN + FF + residual, and their backward counterparts) against the fp64 CPU oracle: output, input gradient
+    and every parameter gradient; and against the unfused HIP path.  grid_cap = 1: ONE workgroup walks all pixel tiles
+    (several passes; for C = 128 the two-slot weight reload of every pass); B*P is not a multiple of 32 in some cases
+    (half-live tiles, tiles spanning images)."""
+    afdm, ops, dev = A
+    B, C, S = case
+    g = _g(1000 + B + C + S)
+    torch.manual_seed(5 + C + S)
+    mod = afdm.SelfAttention(C, S)
+    with torch.no_grad():
+        for q in mod.parameters():                       # biases / LN parameters off their trivial init
+            q.add_(0.1 * torch.randn(q.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    x = torch.randn(B, C, S, S, generator=g)
+    dy = torch.randn(B, C, S, S, generator=g)
+    # fp64 oracle
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    x64 = x.double().requires_grad_(True)
+    y64 = R.self_attention(sd64, "", x64)
+    names = list(sd64)
+    ref = torch.autograd.grad(y64, [x64] + [sd64[k] for k in names], dy.double())
+    mod = mod.to(dev)
+    L = afdm.lib()
+    outs = {}
+    try:
+        for fused in (True, False):
+            afdm.SelfAttention.fused = fused
+            L.afd_debug_tok_grid(grid_cap)
+            xi = x.to(dev).requires_grad_(True)
+            y = mod(xi)
+            params = dict(mod.named_parameters())
+            grads = torch.autograd.grad(y, [xi] + [params[k] for k in names], dy.to(dev))
+            with torch.no_grad():
+                y_inf = mod(x.to(dev))                  # the inference form (nothing saved for backward)
+            outs[fused] = (y.detach().cpu(), [t.cpu() for t in grads], y_inf.cpu())
+    finally:
+        afdm.SelfAttention.fused = True
+        L.afd_debug_tok_grid(0)
+    y, grads, y_inf = outs[True]
+    e_y = rel_l2(y, y64.detach())
+    errs = {"x": rel_l2(grads[0], ref[0])}
+    for k, gk, rk in zip(names, grads[1:], ref[1:]):
+        errs[k] = rel_l2(gk, rk)
+    worst = max(errs, key=errs.get)
+    e_uf = max([rel_l2(y, outs[False][0])] + [rel_l2(a, b) for a, b in zip(grads, outs[False][1])])
+    print(f"fused attention block B{B} C{C} {S}x{S} cap{grid_cap}: fwd {e_y:.2e}, worst grad {worst} {errs[worst]:.2e}, vs unfused {e_uf:.2e}")
+    assert e_y < TOL and errs[worst] < TOL, (e_y, errs)
+    assert torch.equal(y, y_inf)
+    assert e_uf < 5e-6
+
+
+def test_fused_attention_block_full_batch(A):
+    """B = 256 on the Config-D block shapes (sa1..sa6): the fused path against the unfused HIP path (two independent
+    kernel families); covers the grids the train step really launches."""
+    afdm, ops, dev = A
+    worst = 0.0
+    for C, S in ((64, 16), (128, 8), (128, 4), (64, 8), (32, 16), (32, 32)):
+        torch.manual_seed(C + S)
+        mod = afdm.SelfAttention(C, S).to(dev)
+        x = torch.randn(256, C, S, S, device=dev)
+        dy = torch.randn(256, C, S, S, device=dev)
+        res = {}
+        try:
+            for fused in (True, False):
+                afdm.SelfAttention.fused = fused
+                xi = x.clone().requires_grad_(True)
+                y = mod(xi)
+                grads = torch.autograd.grad(y, [xi] + list(mod.parameters()), dy)
+                res[fused] = [y.detach()] + list(grads)
+        finally:
+            afdm.SelfAttention.fused = True
+        e = max(rel_l2(a.cpu(), b.cpu()) for a, b in zip(res[True], res[False]))
+        print(f"full-batch attention block C{C} {S}x{S}: fused vs unfused worst rel-L2 {e:.2e}")
+        worst = max(worst, e)
+    assert worst < 5e-6
+
+
 def test_attention_peaked_softmax_is_stable(A):
     """Forces the running-max rescale branch: one key dominates late in the sequence."""
     _, ops, dev = A
