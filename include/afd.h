@@ -200,6 +200,8 @@ int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float
 int afd_tok_supported(int C);
 /* test hook: cap the workgroups per launch of the four kernels below (forces several passes per workgroup); 0 = default */
 int afd_debug_tok_grid(int max_workgroups);
+/* test hook: 0 = kernel form by the rule, 1 = never the wide (one wave per 32-channel block) forms, 2 = wide wherever they exist */
+int afd_debug_tok_path(int mode);
 int afd_tok_head_fwd(const float* x, const float* gamma, const float* beta, const float* w_in, const float* b_in,
                      float* h_out, float* stats_out, float* qkv, int B, int C, int P, float eps, afd_stream_t stream);
 int afd_tok_tail_fwd(const float* att, const float* x, const float* w_o, const float* b_o, const float* gamma, const float* beta,
