@@ -67,66 +67,174 @@ def ev_time(fn, reps=5, warm=2):
     return a.elapsed_time(b) / reps
 
 
+GN_PLAIN = [(32, 32), (64, 16), (128, 8), (128, 4), (256, 4), (256, 4), (128, 4), (64, 8), (32, 16), (32, 32)]   # GroupNorm sites without F4 (C, side)
+RESAMPLE = [(32, 32), (64, 16), (128, 8)]                # block-level F3 inputs (C, side); F2 runs the same shapes in reverse
+EMB = [64, 128, 128, 64, 32, 32]                         # time-embedding Linear widths (256 -> C)
+N_PARAMS = 5897155
+
+
 def kernel_table(dev, B):
-    """Times each kernel family over the Config-D shapes of one train step (forward + backward)."""
+    """Times EVERY kernel family of one Config-D train step (forward + backward + optimiser) over its real shapes, each
+    through the C-ABI entry point the autograd shells call, with HIP events on the launch stream.  Per family: launches,
+    ms per step, algorithmic flops or bytes, the bound it is priced against and the fraction reached."""
     import afdm
     from afdm import ops
     L, s = afdm.lib(), torch.cuda.current_stream().cuda_stream
     rows = {}
+    P = lambda t: None if t is None else t.data_ptr()
 
-    def add(name, ms, flops=0.0, bytes_=0.0, launches=1):
-        r = rows.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+    def add(name, ms, flops=0.0, bytes_=0.0, launches=1, bound=None, **extra):
+        r = rows.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "bound": bound})
         r["ms"] += ms; r["flops"] += flops; r["bytes"] += bytes_; r["launches"] += launches
+        for k, v in extra.items():
+            r[k] = r.get(k, 0) + v
 
+    def cached(cache, key, fn):
+        if key not in cache:
+            cache[key] = fn()
+        return cache[key]
+
+    # ---- 3x3 convolutions (F5) -----------------------------------------------------------------------------------
     seen = {}
     for (ci, co, S) in CONV3:
-        key = (ci, co, S)
-        if key not in seen:
-            seen[key] = conv_layer_times(L, s, dev, B, ci, co, S)
-        tf, td, tw, wf, wd = seen[key]
+        tf, td, tw, wf, wd = cached(seen, (ci, co, S), lambda: conv_layer_times(L, s, dev, B, ci, co, S))
         fl = 2.0 * B * S * S * ci * co * 9              # algorithmic (direct-form) flops of one pass
-        add("conv3x3_fwd", tf, fl)
+        add("conv3x3_fwd", tf, fl, bound="mfma", wino=wf)
         if ci > 3:
-            add("conv3x3_dgrad", td, fl)
-        add("conv3x3_wgrad", tw, fl)
-        rows["conv3x3_fwd"]["wino"] = rows["conv3x3_fwd"].get("wino", 0) + wf
-        if ci > 3:
-            rows["conv3x3_dgrad"]["wino"] = rows["conv3x3_dgrad"].get("wino", 0) + wd
+            add("conv3x3_dgrad", td, fl, bound="mfma", wino=wd)
+        add("conv3x3_wgrad", tw, fl, bound="mfma", wino=1 if (ci > 3) else 0)
+    # ---- filtered GELU (F4) + the GroupNorm kernels around it (F6) ------------------------------------------------
     seen = {}
-    k = afdm.circularLowpassKernel(math.pi / 2, 3, 2)
-    tk = ops.Taps(k)
+    tk = ops.Taps(afdm.circularLowpassKernel(math.pi / 2, 3, 2))
+
+    def act_site(C, S):
+        x = torch.randn(B, C, S, S, device=dev); y = torch.empty_like(x); dv = torch.empty_like(x); dx = torch.empty_like(x)
+        st = torch.zeros(B, 2, device=dev); st[:, 1] = 1
+        g = torch.ones(C, device=dev); be = torch.zeros(C, device=dev)
+        part = torch.empty(B * C * 2, device=dev); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+        tf = ev_time(lambda: L.afd_filt_act_fwd(P(x), P(y), B, C, S, S, P(st), P(g), P(be), None, tk.ptr, tk.ptr, 3, None, s))
+        tb = ev_time(lambda: L.afd_filt_act_bwd(P(x), P(y), P(dv), B, C, S, S, P(st), P(g), P(be), None, tk.ptr, tk.ptr, 3, None, P(part), s))
+        tg = ev_time(lambda: L.afd_groupnorm1_fwd(P(x), None, P(st), B, C, S * S, 1e-5, None, None, None, 0, None, s))
+        ta = ev_time(lambda: L.afd_groupnorm1_bwd(P(x), P(dv), P(st), B, C, S * S, P(g), P(be), None, 0, P(dx), None, P(part), None, 1, P(dg), P(db), 1, s))
+        return tf, tb, tg, ta
     for (C, S) in ACT_SITES:
-        if (C, S) not in seen:
-            x = torch.randn(B, C, S, S, device=dev); y = torch.empty_like(x); dv = torch.empty_like(x)
-            st = torch.zeros(B, 2, device=dev); st[:, 1] = 1
-            g = torch.ones(C, device=dev); be = torch.zeros(C, device=dev)
-            tf = ev_time(lambda: L.afd_filt_act_fwd(x.data_ptr(), y.data_ptr(), B, C, S, S, st.data_ptr(), g.data_ptr(), be.data_ptr(), None, tk.ptr, tk.ptr, 3, None, s))
-            tb = ev_time(lambda: L.afd_filt_act_bwd(x.data_ptr(), y.data_ptr(), dv.data_ptr(), B, C, S, S, st.data_ptr(), g.data_ptr(), be.data_ptr(), None, tk.ptr, tk.ptr, 3, None, None, s))
-            tg = ev_time(lambda: L.afd_groupnorm1_fwd(x.data_ptr(), None, st.data_ptr(), B, C, S * S, 1e-5, None, None, None, 0, None, s))
-            seen[(C, S)] = (tf, tb, tg)
-            del x, y, dv
-        tf, tb, tg = seen[(C, S)]
+        tf, tb, tg, ta = cached(seen, (C, S), lambda: act_site(C, S))
         e = float(B) * C * S * S
-        add("filt_act_fwd_n3", tf, bytes_=8 * e)
-        add("filt_act_bwd_n3", tb, bytes_=12 * e)
-        add("groupnorm1_stats", tg, bytes_=4 * e)
+        add("filt_act_fwd_n3", tf, bytes_=8 * e, bound="hbm")
+        add("filt_act_bwd_n3", tb, bytes_=12 * e, bound="hbm")
+        add("groupnorm1_stats", tg, bytes_=4 * e, bound="hbm")
+        add("groupnorm1_bwd_apply", ta, bytes_=12 * e, bound="hbm")
+    seen = {}
+
+    def gn_site(C, S):
+        x = torch.randn(B, C, S, S, device=dev); y = torch.empty_like(x); dx = torch.empty_like(x)
+        st = torch.empty(B, 2, device=dev); g = torch.ones(C, device=dev); be = torch.zeros(C, device=dev)
+        emb = torch.randn(B, C, device=dev); demb = torch.empty(B, C, device=dev)
+        part = torch.empty(B * C * 2, device=dev); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+        tf = ev_time(lambda: L.afd_groupnorm1_fwd(P(x), P(y), P(st), B, C, S * S, 1e-5, P(g), P(be), None, 0, P(emb), s))
+        tb = ev_time(lambda: L.afd_groupnorm1_bwd(P(x), P(y), P(st), B, C, S * S, P(g), P(be), None, 0, P(dx), None, P(part), P(demb), 0, P(dg), P(db), 1, s))
+        return tf, tb
+    for (C, S) in GN_PLAIN:
+        tf, tb = cached(seen, (C, S), lambda: gn_site(C, S))
+        e = float(B) * C * S * S
+        add("groupnorm1_fwd_full", tf, bytes_=8 * e, bound="hbm")
+        add("groupnorm1_bwd_full", tb, bytes_=20 * e, launches=2, bound="hbm")          # plane sums (x, dy) + apply (x, dy -> dx)
+    # ---- block-level filtered resampling (F2 / F3) and the concat copy --------------------------------------------
+    for (C, S) in RESAMPLE:
+        x = torch.randn(B, C, S, S, device=dev); y = torch.empty(B, C, S // 2, S // 2, device=dev)
+        e_hi, e_lo = float(B) * C * S * S, float(B) * C * S * S / 4
+        add("filt_down2_fwd", ev_time(lambda: L.afd_filt_down2_fwd(P(x), P(y), B, C, S, S, 0, 0, tk.ptr, 3, s)), bytes_=4 * (e_hi + e_lo), bound="hbm")
+        add("filt_down2_bwd", ev_time(lambda: L.afd_filt_down2_bwd(P(y), P(x), B, C, S, S, 0, 0, tk.ptr, 3, s)), bytes_=4 * (e_hi + e_lo), bound="hbm")
+        add("filt_up2_fwd", ev_time(lambda: L.afd_filt_up2_fwd(P(y), P(x), B, C, S // 2, S // 2, 0, 0, tk.ptr, 3, s)), bytes_=4 * (e_hi + e_lo), bound="hbm")
+        add("filt_up2_bwd", ev_time(lambda: L.afd_filt_up2_bwd(P(x), P(y), B, C, S // 2, S // 2, 0, 0, tk.ptr, 3, s)), bytes_=4 * (e_hi + e_lo), bound="hbm")
+        add("concat_copy", 2 * ev_time(lambda: L.afd_copy_batched(P(x), P(x), B, C * S * S, 0, 0, s)), bytes_=2 * 8 * e_hi, launches=2, bound="hbm")
+        del x, y
+    # ---- attention blocks (F10): core + the fused token-wise chains + their parameter gradients --------------------
     for (C, S) in ATTN:
         Lq = S * S
         qkv = torch.randn(B, 3 * C, S, S, device=dev); o = torch.empty(B, C, S, S, device=dev)
         lse = torch.empty(B, 4, Lq, device=dev); dq = torch.empty_like(qkv); dl = torch.empty_like(lse)
-        tf = ev_time(lambda: L.afd_attn_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, 4, C // 4, Lq, s), reps=3, warm=1)
-        tb = ev_time(lambda: L.afd_attn_bwd(qkv.data_ptr(), o.data_ptr(), o.data_ptr(), lse.data_ptr(), dq.data_ptr(), dl.data_ptr(), B, 4, C // 4, Lq, s), reps=3, warm=1)
+        tf = ev_time(lambda: L.afd_attn_fwd(P(qkv), P(o), P(lse), B, 4, C // 4, Lq, s), reps=3, warm=1)
+        tb = ev_time(lambda: L.afd_attn_bwd(P(qkv), P(o), P(o), P(lse), P(dq), P(dl), B, 4, C // 4, Lq, s), reps=3, warm=1)
         fl = 4.0 * B * Lq * Lq * C
-        add("attn_fwd", tf, fl)
-        add("attn_bwd", tb, 2.5 * fl, launches=2)
-        del qkv, o, lse, dq
+        add("attn_fwd", tf, fl, bound="mfma")
+        add("attn_bwd", tb, 2.5 * fl, launches=2, bound="mfma")
+        # token-wise chains
+        x = torch.randn(B, C, S, S, device=dev)
+        mk = lambda *sh: torch.randn(*sh, device=dev) * 0.1
+        g1, b1_, w_in, b_in = 1 + mk(C), mk(C), mk(3 * C, C), mk(3 * C)
+        wo, bo, g2, be2, w1, b1, w2, b2 = mk(C, C), mk(C), 1 + mk(C), mk(C), mk(C, C), mk(C), mk(C, C), mk(C)
+        h, st = torch.empty_like(x), torch.empty(B, Lq, 2, device=dev)
+        a, f, u, g, out = (torch.empty_like(x) for _ in range(5))
+        st2 = torch.empty(B, Lq, 2, device=dev)
+        du, df, da, datt, dh, dx = (torch.empty_like(x) for _ in range(6))
+        e, flc = 4.0 * B * C * Lq, 2.0 * B * Lq * C * C
+        if L.afd_tok_supported(C):
+            add("tok_head_fwd", ev_time(lambda: L.afd_tok_head_fwd(P(x), P(g1), P(b1_), P(w_in), P(b_in), P(h), P(st), P(qkv), B, C, Lq, 1e-5, s)),
+                3 * flc, 5 * e, bound="hbm")
+            add("tok_tail_fwd", ev_time(lambda: L.afd_tok_tail_fwd(P(o), P(x), P(wo), P(bo), P(g2), P(be2), P(w1), P(b1), P(w2), P(b2), P(a), P(st2), P(f), P(u),
+                                                                    P(g), P(out), B, C, Lq, 1e-5, s)), 3 * flc, 7 * e, bound="hbm")
+            add("tok_tail_bwd", ev_time(lambda: L.afd_tok_tail_bwd(P(out), P(u), P(a), P(st2), P(g2), P(w2), P(w1), P(wo), P(du), P(df), P(da), P(datt), B, C, Lq, s)),
+                3 * flc, 7 * e, bound="hbm")
+            add("tok_head_bwd", ev_time(lambda: L.afd_tok_head_bwd(P(dq), P(x), P(st), P(g1), P(w_in), P(da), P(dh), P(dx), B, C, Lq, s)), 3 * flc, 7 * e, bound="hbm")
+        ws = torch.empty(max(L.afd_conv_wgrad_workspace_bytes(B, C, 3 * C, S, S, 1), L.afd_conv_wgrad_workspace_bytes(B, C, C, S, S, 1), 4) // 4, device=dev)
+        dw3, db3, dwc, dbc = torch.empty(3 * C, C, device=dev), torch.empty(3 * C, device=dev), torch.empty(C, C, device=dev), torch.empty(C, device=dev)
+        t_w = ev_time(lambda: L.afd_conv_wgrad(P(h), P(dq), P(dw3), P(db3), B, C, 3 * C, S, S, 1, 0, P(ws), s))
+        t_w += 3 * ev_time(lambda: L.afd_conv_wgrad(P(f), P(du), P(dwc), P(dbc), B, C, C, S, S, 1, 0, P(ws), s))
+        add("linear_wgrad", t_w, 6 * flc, (5 + 3 * 2) * e, launches=4, bound="hbm")
+        part = torch.empty(B, 2, C, device=dev)
+        add("layernorm_params", 2 * ev_time(lambda: L.afd_layernorm_c_bwd_params(P(x), P(dh), P(st), B, C, Lq, P(part), P(dbc), P(dbc), 0, s)), bytes_=2 * 2 * e,
+            launches=2, bound="hbm")
+        del qkv, o, lse, dq, x, h, a, f, u, g, out, du, df, da, datt, dh, dx
+    # ---- time embedding, loss, optimiser -------------------------------------------------------------------------
+    temb = torch.randn(B, 256, device=dev)
+    for C in EMB:
+        w, b = torch.randn(C, 256, device=dev), torch.randn(C, device=dev)
+        o, dw, db = torch.empty(B, C, device=dev), torch.empty(C, 256, device=dev), torch.empty(C, device=dev)
+        add("silu_linear_fwd", ev_time(lambda: L.afd_silu_linear_fwd(P(temb), P(w), P(b), P(o), B, 256, C, s)), 2.0 * B * 256 * C, bound="hbm",
+            bytes_=4.0 * (B * 256 + 256 * C + B * C))
+        add("silu_linear_bwd", ev_time(lambda: L.afd_silu_linear_bwd(P(temb), P(w), P(o), P(dw), P(db), None, B, 256, C, 0, s)), 2.0 * B * 256 * C, bound="hbm",
+            bytes_=4.0 * (B * 256 + 256 * C + B * C))
+    n_img = B * 3 * 32 * 32
+    xi, ei = torch.randn(n_img, device=dev), torch.randn(n_img, device=dev)
+    loss, wsl = torch.empty(1, device=dev), torch.empty(4096, device=dev)
+    add("mse_fwd_bwd", ev_time(lambda: (L.afd_mse_fwd(P(xi), P(ei), P(loss), P(wsl), n_img, s), L.afd_mse_bwd(P(xi), P(ei), P(loss), P(xi), n_img, s))),
+        bytes_=4.0 * 5 * n_img, launches=2, bound="hbm")
+    pf, gf, mf, vf = (torch.zeros(N_PARAMS, device=dev) for _ in range(4))
+    stt = torch.zeros(4, device=dev)
+
+    def adam():
+        L.afd_adamw_tick(P(stt), 0.9, 0.999, s)
+        L.afd_adamw_step(P(pf), P(gf), P(mf), P(vf), N_PARAMS, P(stt), 3e-4, 0.9, 0.999, 1e-8, 0.01, 1.0, s)
+    add("adamw", ev_time(adam), bytes_=28.0 * N_PARAMS, launches=2, bound="hbm")
+    # ---- Config E: the per-step rotation of sampling (not part of the train step) -----------------------------------
+    xr = torch.randn(B, 3, 32, 32, device=dev)
+    t_rot = ev_time(lambda: ops.rotate_spline3_wrap(xr, 0.09))
     torch.cuda.synchronize()
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_families.json")))
+    except Exception:
+        pass
     out = []
     for name, r in rows.items():
         sec = r["ms"] * 1e-3
-        out.append({"kernel": name, "launches_per_step": r["launches"], "winograd_launches": r.get("wino"), "ms_per_step": round(r["ms"], 4),
-                    "tflops": round(r["flops"] / sec / 1e12, 3) if r["flops"] else None,
-                    "gbs": round(r["bytes"] / sec / 1e9, 1) if r["bytes"] else None})
+        tf = r["flops"] / sec / 1e12 if r["flops"] else None
+        gb = r["bytes"] / sec / 1e9 if r["bytes"] else None
+        frac = (tf / MFMA_F32_PEAK_TF) if r["bound"] == "mfma" else (gb / HBM_PEAK_GBS if gb else None)
+        row = {"kernel": name, "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 4), "bound": r["bound"],
+               "tflops": round(tf, 3) if tf else None, "gbs": round(gb, 1) if gb else None, "frac": round(frac, 4) if frac else None}
+        if "wino" in r:
+            # Winograd F(2x2,3x3) / F(3x3,2x2) issues 16 of the direct form's 36 multiplies: the fraction of the matrix peak the
+            # EXECUTED multiplies reach (launch-weighted: the few direct-form launches count in full)
+            row["winograd_launches"] = r["wino"]
+            row["frac_executed"] = round(frac * (16.0 / 36.0 * r["wino"] + (r["launches"] - r["wino"])) / r["launches"], 4)
+        if name in pmc and pmc[name].get("mfma_busy_frac") is not None:
+            row["mfma_busy_pmc"] = pmc[name]["mfma_busy_frac"]
+        out.append(row)
+    out.sort(key=lambda z: -z["ms_per_step"])
+    out.append({"kernel": "affine_spline3_wrap (Config E sampling, per denoise step; not in the train step)", "launches_per_step": 0,
+                "ms_per_step": round(t_rot, 4), "bound": "fp64 vector", "gbs": round(8.0 * xr.numel() / (t_rot * 1e-3) / 1e9, 1)})
     return out, rows
 
 
@@ -381,33 +489,33 @@ def main():
                                                       "n_per_gpu": NS * n, "streams": NS, "seconds": round(cdt, 3)}
 
     if rank == 0 and world == 1:
-        if not args.no_kernels:
+        if not args.no_kernels and args.variant == 3:       # (the family table is written over Config D's layer shapes)
             log("per-kernel timing")
             table, rows = kernel_table(dev, args.batch)
-            dom = max(rows.items(), key=lambda kv: kv[1]["ms"])
-            name, r = dom
-            sec = r["ms"] * 1e-3
+            trow = table[0]                              # arg-max of ms/step over ALL timed families
+            name, r = trow["kernel"], rows[table[0]["kernel"]]
             traffic, tsrc = pmc_traffic(name, r["launches"])
-            if r["flops"]:
+            sec = r["ms"] * 1e-3
+            if r["bound"] == "mfma":
                 ach = r["flops"] / sec / 1e12
-                result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF,
-                                      "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": traffic,
+                basis = ("algorithmic direct-form flops (2*9*Cin*Cout per output pixel, SURVEY 8d) / HIP-event time; the Winograd kernels issue 16/36 of "
+                         "those multiplies on the fp32 MFMA (frac_executed), so frac is not bounded by 1"
+                         + ("; weight-gradient launches are sized to run on a second stream beside the backward chain, so timed alone, as here, they "
+                            "do not fill the chip" if name == "conv3x3_wgrad" else "")) if name.startswith("conv") else \
+                        ("algorithmic attention flops (4*L*L*C forward, 2.5x that backward, SURVEY 8d) / HIP-event time; fp32 results; head dim 8: "
+                         "d-contractions as 3-piece bf16 splits on the matrix cores (fp32-exact), rank-8 updates and softmax on the vector pipe; "
+                         "priced against the fp32 matrix peak")
+                result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                      "frac": round(ach / MFMA_F32_PEAK_TF, 4), "frac_executed": trow.get("frac_executed"),
+                                      "mfma_busy_pmc": trow.get("mfma_busy_pmc"), "traffic": traffic,
                                       "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3),
-                                      "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
-                                      "basis": ("algorithmic direct-form flops (2*9*Cin*Cout per output pixel, SURVEY 8d) / HIP-event time; "
-                                                "the Winograd kernels issue 16/36 of those multiplies on the fp32 MFMA, so frac is not bounded by 1"
-                                                + ("; weight-gradient launches are sized (128 workgroups) to run on a second stream beside the backward chain "
-                                                   "(whole step 9.83 -> 9.67 ms against 256-workgroup launches), so timed alone, as here, they fill half the CUs"
-                                                   if name == "conv3x3_wgrad" else ""))
-                                               if name.startswith("conv") else
-                                               ("algorithmic attention flops (4*L*L*C forward, 2.5x that backward, SURVEY 8d) / HIP-event time; "
-                                                "fp32 results; head dim 8: d-contractions as 3-piece bf16 splits on the matrix cores (fp32-exact), rank-8 updates and softmax on the vector pipe; priced against the fp32 matrix peak"),
-                                      "traffic_source": tsrc}
+                                      "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2), "basis": basis, "traffic_source": tsrc}
             else:
                 ach = r["bytes"] / sec / 1e9
                 result["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                                      "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3), "traffic_source": tsrc}
+                                      "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3),
+                                      "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2), "traffic_source": tsrc}
             result["kernels"] = table
         if not args.no_cpu_baseline:
             log(f"CPU baseline on {host_threads()} host threads")
