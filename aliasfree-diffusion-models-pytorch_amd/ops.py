@@ -181,7 +181,10 @@ class _GradMode:
     that stream -- forked after dY exists, joined by the caller before the optimizer -- and fill the CUs that the
     dependent chain of small dgrad / norm kernels leaves idle.  Legal under stream capture (fork / join by events)."""
     inplace = False
-    side = None
+    side = None           # first side stream (None: no side stream) -- what the ops test to decide whether to defer
+    sides = []            # all side streams: queued launches are dealt to them in turn (one in-order stream runs ONE
+    #                       weight-gradient kernel at a time; two let a layer's slab reduce overlap the next layer's multiplies)
+    turn = 0
     pending = []          # (launch closure, tensors it reads): parameter-gradient kernels not launched yet
     launched = []         # the same pairs after launch, held until the join (their buffers are in use on the side stream)
     batch = 8             # fork the side stream once per this many layers (few cross-stream edges in a captured graph)
@@ -208,13 +211,22 @@ def defer_to_side_stream(fn, *keep, writes=()):
 
 def flush_wgrads():
     """Launch the queued parameter-gradient kernels on the side stream (one fork for the whole batch)."""
-    side, q = _GradMode.side, _GradMode.pending
+    sides, q = _GradMode.sides, _GradMode.pending
     if not q:
         return
-    side.wait_stream(torch.cuda.current_stream())                             # fork: every queued dY (and the zeroed .grad) exists
-    with torch.cuda.stream(side):
-        for fn, _, _ in q:
-            fn(side.cuda_stream)
+    cur = torch.cuda.current_stream()
+    lanes = [[] for _ in sides]
+    for item in q:
+        lanes[_GradMode.turn % len(sides)].append(item)
+        _GradMode.turn += 1
+    for side, items in zip(sides, lanes):
+        if not items:
+            continue
+        side.wait_stream(cur)                                                 # fork: every queued dY (and the zeroed .grad) exists
+        with torch.cuda.stream(side):
+            h = side.cuda_stream
+            for fn, _, _ in items:
+                fn(h)
     _GradMode.launched.extend(q)
     _GradMode.pending = []
     if _GradMode.on_write is not None:
@@ -226,17 +238,21 @@ class inplace_param_grads:
         self.side_stream, self.batch, self.on_write = side_stream, batch, on_write
 
     def __enter__(self):
-        self.prev, self.prev_side, self.prev_cb = _GradMode.inplace, _GradMode.side, _GradMode.on_write
-        _GradMode.inplace, _GradMode.side, _GradMode.batch, _GradMode.on_write = True, self.side_stream, self.batch, self.on_write
+        self.prev, self.prev_side, self.prev_sides, self.prev_cb = _GradMode.inplace, _GradMode.side, _GradMode.sides, _GradMode.on_write
+        ss = self.side_stream
+        self.streams = [] if ss is None else (list(ss) if isinstance(ss, (list, tuple)) else [ss])
+        _GradMode.inplace, _GradMode.batch, _GradMode.on_write = True, self.batch, self.on_write
+        _GradMode.sides, _GradMode.side, _GradMode.turn = self.streams, (self.streams[0] if self.streams else None), 0
 
     def __exit__(self, exc_type, *a):
-        if self.side_stream is not None:
+        if self.streams:
             if exc_type is not None:
                 _GradMode.pending = []                                       # backward failed: drop what was queued
             flush_wgrads()
-            torch.cuda.current_stream().wait_stream(self.side_stream)        # join: every dW is in .grad
+            for st in self.streams:
+                torch.cuda.current_stream().wait_stream(st)                  # join: every dW is in .grad
             _GradMode.launched = []                                          # buffers may be freed now (main-stream order)
-        _GradMode.inplace, _GradMode.side, _GradMode.on_write = self.prev, self.prev_side, self.prev_cb
+        _GradMode.inplace, _GradMode.side, _GradMode.sides, _GradMode.on_write = self.prev, self.prev_side, self.prev_sides, self.prev_cb
 
 
 def _direct(*params):

@@ -201,8 +201,8 @@ class GradAllReduce:
             self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
             return
         self.comm.wait_stream(torch.cuda.current_stream())
-        if self.side is not None:
-            self.comm.wait_stream(self.side)
+        for st in (self.side or ()):
+            self.comm.wait_stream(st)
         with torch.cuda.stream(self.comm):
             if self.via_host:
                 h = buf.to("cpu", non_blocking=False)
@@ -248,7 +248,8 @@ class TrainStep:
         # 9.77 / 9.67 / 9.66 / 9.87 / 9.95 ms.  Stream priorities (side high, or main high) both measured slower.
         if overlap_wgrad is None:
             overlap_wgrad = True
-        self.wgrad_stream = torch.cuda.Stream() if overlap_wgrad else None
+        n_side = int(os.environ.get("AFD_WGRAD_STREAMS", 1))                                # side streams (tuning hook)
+        self.wgrad_stream = [torch.cuda.Stream() for _ in range(max(1, n_side))] if overlap_wgrad else None
         self.wgrad_batch = int(os.environ.get("AFD_WGRAD_BATCH", 16 if graph else 4))      # layers per fork (tuning hook)
         self.opt = FusedAdamW(model, lr=lr)
         want_ddp = distributed if distributed is not None else dist.is_initialized()
