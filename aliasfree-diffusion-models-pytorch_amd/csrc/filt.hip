@@ -146,56 +146,56 @@ __global__ void gelu_grad_mul_gen(const float* __restrict__ u, float* __restrict
 
 // ------------------------------------------------------------------------------------------
 // exact-GELU by table: the fused kernels are bound by vector instructions (4 GELUs per element), and the rcp + exp
-// form of erf costs ~19 of them.  Both GELU(u) = u (1/2 + e(|u|) sgn u) and GELU'(u) = 1/2 + h(|u|) sgn u are an odd
-// function of u around 1/2: e(a) = Phi(a) - 1/2, h(a) = e(a) + a phi(a).  Each is tabulated on [0, 6) as 96 cubic
-// Hermite pieces of width 1/16 (coefficients from fp64 erf / exp: interpolation error <= 2.2e-8 and 1.2e-7, below the
-// 6e-7 of the A&S form it replaces; beyond 6 both are 1/2 to 4e-8), copied to LDS by every workgroup: a lookup is one
-// ds_read_b128 (neighbouring pixels mostly hit the same piece: broadcast) + 3 fma, ~11 vector instructions per GELU.
+// form of erf costs ~19 of them.  GELU(u) = u Phi(u) and GELU'(u) = Phi(u) + u phi(u): Phi and GELU' are tabulated over
+// SIGNED u on [-6, 6) as 192 cubic Hermite pieces of width 1/16 each (coefficients from fp64 erf / exp: interpolation
+// error <= 2.2e-8 and 1.2e-7, below the 6e-7 of the A&S form it replaces; beyond +-6 both are 0 / 1 to 1e-9), copied to
+// LDS by every workgroup: a lookup is fma + clamp + cvt + shift + fract, one ds_read_b128 (neighbouring pixels mostly
+// hit the same piece: broadcast) and 3 fma -- 9 vector instructions per GELU, 8 per GELU' (the unsigned |u| tables of
+// the first version needed a copysign and a recombination with u/2 on top: 11 / 10).
 // The table is produced ON THE DEVICE by a one-thread-per-piece kernel at first use -- a launch, so it is legal under
 // stream capture and allocates nothing (static device storage).
 // ------------------------------------------------------------------------------------------
-constexpr int kGeluPieces = 96;
-constexpr float kGeluScale = 16.f;
-__device__ float4 g_gelu_tab[2 * kGeluPieces];        // [0, 96): e pieces; [96, 192): h pieces
+constexpr int kGeluPieces = 192;
+constexpr float kGeluScale = 16.f, kGeluOffset = 96.f;
+__device__ float4 g_gelu_tab[2 * kGeluPieces];        // [0, 192): Phi pieces; [192, 384): GELU' pieces
 
 __global__ void gelu_table_init() {
   const int i = threadIdx.x;
   if (i >= kGeluPieces) return;
-  const double hstep = 1.0 / 16.0, a0 = i * hstep, a1 = a0 + hstep;
+  const double hstep = 1.0 / 16.0, a0 = (i - 96) * hstep, a1 = a0 + hstep;
   const double isq2 = 0.70710678118654752440, isq2pi = 0.39894228040143267794;
   auto phi = [&](double a) { return isq2pi * exp(-0.5 * a * a); };
-  auto e = [&](double a) { return 0.5 * erf(a * isq2); };
-  auto hfun = [&](double a) { return e(a) + a * phi(a); };
-  auto hder = [&](double a) { return (2.0 - a * a) * phi(a); };
+  auto Phi = [&](double a) { return 0.5 * erfc(-a * isq2); };
+  auto gfun = [&](double a) { return Phi(a) + a * phi(a); };          // GELU'
+  auto gder = [&](double a) { return (2.0 - a * a) * phi(a); };       // GELU''
   {
-    const double f0 = e(a0), f1 = e(a1), d0 = hstep * phi(a0), d1 = hstep * phi(a1);
+    const double f0 = Phi(a0), f1 = Phi(a1), d0 = hstep * phi(a0), d1 = hstep * phi(a1);
     g_gelu_tab[i] = make_float4((float)f0, (float)d0, (float)(3.0 * (f1 - f0) - 2.0 * d0 - d1), (float)(2.0 * (f0 - f1) + d0 + d1));
   }
   {
-    const double f0 = hfun(a0), f1 = hfun(a1), d0 = hstep * hder(a0), d1 = hstep * hder(a1);
+    const double f0 = gfun(a0), f1 = gfun(a1), d0 = hstep * gder(a0), d1 = hstep * gder(a1);
     g_gelu_tab[kGeluPieces + i] = make_float4((float)f0, (float)d0, (float)(3.0 * (f1 - f0) - 2.0 * d0 - d1), (float)(2.0 * (f0 - f1) + d0 + d1));
   }
 }
 static void ensure_gelu_table(hipStream_t s) {
   static bool done = false;
   if (done) return;
-  hipLaunchKernelGGL(gelu_table_init, dim3(1), dim3(128), 0, s);
+  hipLaunchKernelGGL(gelu_table_init, dim3(1), dim3(256), 0, s);
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   // a captured launch only runs at replay: keep launching (12 us once per call) until one eager launch has happened
   if (hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusNone) done = true;
 }
-// odd-part lookup: T[piece](t), piece = floor(16 |u|) clamped, t = frac
-__device__ __forceinline__ float gelu_odd_part(float u, const float4* __restrict__ T) {
-  const float sx = fminf(fabsf(u) * kGeluScale, (float)kGeluPieces - 0.001f);
+// T[piece](t), piece = floor(16 u + 96) clamped to the table, t = frac
+__device__ __forceinline__ float gelu_piece(float u, const float4* __restrict__ T) {
+  const float sx = __builtin_amdgcn_fmed3f(fmaf(u, kGeluScale, kGeluOffset), 0.f, (float)kGeluPieces - 0.001f);
   const float4 c = T[(int)sx];
   const float t = __builtin_amdgcn_fractf(sx);
-  const float v = fmaf(fmaf(fmaf(c.w, t, c.z), t, c.y), t, c.x);
-  return copysignf(v, u);
+  return fmaf(fmaf(fmaf(c.w, t, c.z), t, c.y), t, c.x);
 }
-__device__ __forceinline__ float gelu_tab(float u, const float4* __restrict__ T) { return fmaf(u, gelu_odd_part(u, T), 0.5f * u); }
-__device__ __forceinline__ float gelu_grad_tab(float u, const float4* __restrict__ T) { return 0.5f + gelu_odd_part(u, T + kGeluPieces); }
+__device__ __forceinline__ float gelu_tab(float u, const float4* __restrict__ T) { return u * gelu_piece(u, T); }
+__device__ __forceinline__ float gelu_grad_tab(float u, const float4* __restrict__ T) { return gelu_piece(u, T + kGeluPieces); }
 __device__ __forceinline__ void load_gelu_table(float4* __restrict__ T, int first, int count) {   // 256-thread workgroups
-  if ((int)threadIdx.x < count) T[threadIdx.x] = g_gelu_tab[first + threadIdx.x];
+  for (int i = threadIdx.x; i < count; i += 256) T[i] = g_gelu_tab[first + i];
   __syncthreads();
 }
 
@@ -215,18 +215,28 @@ struct Lane {
   }
   __device__ float left(float v) const { const float s = lane_left(v); return col == 0 ? 0.f : s; }
   __device__ float right(float v) const { const float s = lane_right(v); return col == S - 1 ? 0.f : s; }
+  // the same in two halves, so that a pipelined kernel can request the shuffle in one stage and consume it in the next
+  __device__ float left_mask(float raw) const { return col == 0 ? 0.f : raw; }
+  __device__ float right_mask(float raw) const { return col == S - 1 ? 0.f : raw; }
 };
 
+// FULL (every fast-path kernel): the launch has no dead lanes (planes % planes-per-wave == 0 -- every production shape), so
+// the per-row `if (live)` around loads and stores folds away.  With it each unrolled row is its own basic block (an
+// exec-mask branch per store) and the compiler cannot move the next row's shuffles / table reads above the current
+// row's arithmetic: every row then pays its three or four dependent LDS round trips in full (measured on the filtered
+// GELU: 326 s_waitcnt in a 32-row kernel, vector pipe 64 % busy at 5 waves per SIMD).
 // F2 fast: each lane writes its 2x2 polyphase block per input row as two float2 stores.
-template <int S>
+template <int S, bool FULL>
 __global__ __launch_bounds__(256) void up2_fwd_n3(const float* __restrict__ x, float* __restrict__ y,
                                                   long planes, int C, long xbs, long ybs, Taps3 t) {
   Lane<S> L(planes);
+  if (FULL && !L.live) return;            // a whole wave beyond the last plane (the grid is rounded up to 4 waves): wave-uniform
+  const bool live = FULL || L.live;
   const long b = L.plane / C; const int c = L.plane % C;
   const float* xp = x + b * xbs + (long)c * S * S + L.col;
   float xv[S + 1];
 #pragma unroll
-  for (int i = 0; i < S; ++i) xv[i] = L.live ? xp[i * S] : 0.f;
+  for (int i = 0; i < S; ++i) xv[i] = live ? xp[i * S] : 0.f;
   xv[S] = 0.f;
   float2* yp = reinterpret_cast<float2*>(y + b * ybs + (long)c * 4 * S * S) + L.col;
   float xr = L.right(xv[0]);
@@ -239,16 +249,18 @@ __global__ __launch_bounds__(256) void up2_fwd_n3(const float* __restrict__ x, f
     r0.y = t.k[3] * xe + t.k[5] * xr;                               // U[2i,   2j+1]
     r1.x = t.k[1] * xe + t.k[7] * xd;                               // U[2i+1, 2j]
     r1.y = t.k[0] * xe + t.k[2] * xr + t.k[6] * xd + t.k[8] * xdr;  // U[2i+1, 2j+1]
-    if (L.live) { yp[(2 * i) * S] = r0; yp[(2 * i + 1) * S] = r1; }
+    if (live) { yp[(2 * i) * S] = r0; yp[(2 * i + 1) * S] = r1; }
     xr = xdr;
   }
 }
 
 // F3 fast: input plane is 2S x 2S, lane j owns input columns 2j, 2j+1 (float2 loads).
-template <int S>   // S = OUTPUT side
+template <int S, bool FULL>   // S = OUTPUT side
 __global__ __launch_bounds__(256) void down2_fwd_n3(const float* __restrict__ x, float* __restrict__ y,
                                                     long planes, int C, long xbs, long ybs, Taps3 t) {
   Lane<S> L(planes);
+  if (FULL && !L.live) return;            // a whole wave beyond the last plane (the grid is rounded up to 4 waves): wave-uniform
+  const bool live = FULL || L.live;
   const long b = L.plane / C; const int c = L.plane % C;
   const float2* xp = reinterpret_cast<const float2*>(x + b * xbs + (long)c * 4 * S * S) + L.col;
   float* yp = y + b * ybs + (long)c * S * S + L.col;
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(256) void down2_fwd_n3(const float* __restrict__ x,
   float prev_l = 0.f;
   float2 rows[2 * S];
 #pragma unroll
-  for (int r = 0; r < 2 * S; ++r) rows[r] = L.live ? xp[r * S] : make_float2(0.f, 0.f);
+  for (int r = 0; r < 2 * S; ++r) rows[r] = live ? xp[r * S] : make_float2(0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < S; ++i) {
     const float2 mid = rows[2 * i], nxt = rows[2 * i + 1];
@@ -264,13 +276,30 @@ __global__ __launch_bounds__(256) void down2_fwd_n3(const float* __restrict__ x,
     const float d = t.k[0] * prev_l + t.k[1] * prev.x + t.k[2] * prev.y
                   + t.k[3] * mid_l  + t.k[4] * mid.x  + t.k[5] * mid.y
                   + t.k[6] * nxt_l  + t.k[7] * nxt.x  + t.k[8] * nxt.y;
-    if (L.live) yp[i * S] = d;
+    if (live) yp[i * S] = d;
     prev = nxt; prev_l = nxt_l;
   }
 }
 
+// ---- the filtered GELU as a three-stage software pipeline over the rows of a column ---------------------------------
+// A row's work is a chain through THREE dependent LDS round trips: the right-neighbour shuffle of x (for U11), the four
+// table reads of the GELU pieces, the left-neighbour shuffles of g01 / g11 (for the 3x3 down filter).  Issued in plain
+// program order every row waits for each of them in turn (~4 x 100+ cycles against ~270 cycles of arithmetic: the vector
+// pipe was 64 % busy at 5 waves per SIMD).  Here row k's table reads, row k-1's interpolation + shuffles and row k-2's
+// output taps are interleaved in one unrolled stream, so every LDS result is consumed one full row of arithmetic after
+// it was requested (counted s_waitcnt: younger requests stay in flight).
+struct ActRow { float U[4], t[4]; float4 c[4]; };            // stage 1: filter outputs on the 2x grid, table pieces requested
+struct ActG { float g00, g01, g10, g11, g01l, g11l; };       // stage 2: GELU values + the left neighbours' odd columns
+
+__device__ __forceinline__ void act_lookup(float U, const float4* __restrict__ T, float& t, float4& c) {
+  const float sx = __builtin_amdgcn_fmed3f(fmaf(U, kGeluScale, kGeluOffset), 0.f, (float)kGeluPieces - 0.001f);
+  c = T[(int)sx];
+  t = __builtin_amdgcn_fractf(sx);
+}
+__device__ __forceinline__ float act_cubic(const float4& c, float t) { return fmaf(fmaf(fmaf(c.w, t, c.z), t, c.y), t, c.x); }
+
 // F4 fast forward: y = down2(gelu(up2(v))), v = prologue(x).
-template <int S>
+template <int S, bool FULL>
 __global__ __launch_bounds__(256) void filt_act_fwd_n3(const float* __restrict__ x, float* __restrict__ y,
                                                        long planes, int C, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -280,28 +309,60 @@ __global__ __launch_bounds__(256) void filt_act_fwd_n3(const float* __restrict__
   Lane<S> L(planes);
   const long b = L.plane / C; const int c = L.plane % C;
   const long base = L.plane * (long)S * S + L.col;
+  if (FULL && !L.live) return;            // a whole wave beyond the last plane (the grid is rounded up to 4 waves): wave-uniform
+  const bool live = FULL || L.live;
   float sc, sh;
-  if (L.live) plane_affine(stats, gamma, beta, b, c, sc, sh); else { sc = 1.f; sh = 0.f; }
-  float xv[S + 1];
+  if (live) plane_affine(stats, gamma, beta, b, c, sc, sh); else { sc = 1.f; sh = 0.f; }
+  float xv[S + 2];
 #pragma unroll
-  for (int i = 0; i < S; ++i) xv[i] = L.live ? prologue(x, base + i * S, sc, sh, res) : 0.f;
-  xv[S] = 0.f;
+  for (int i = 0; i < S; ++i) xv[i] = live ? fmaf(x[base + i * S], sc, sh) : 0.f;
+  if (res) {                                       // ONE uniform branch around all residual loads (not one per row)
+#pragma unroll
+    for (int i = 0; i < S; ++i) xv[i] += live ? res[base + i * S] : 0.f;
+  }
+  xv[S] = 0.f; xv[S + 1] = 0.f;
+  ActRow row[2];
+  ActG gg[2];
   float g10p = 0.f, g11p = 0.f, g11lp = 0.f;       // odd row of the previous input row (G[2i-1, .])
-  float xr = L.right(xv[0]);
+  float xr0 = L.right(xv[0]), xr1 = lane_right(xv[1]);    // right neighbours of rows k, k + 1 (rolling; xr1 still unmasked)
 #pragma unroll
-  for (int i = 0; i < S; ++i) {
-    const float xe = xv[i], xd = xv[i + 1];
-    const float xdr = L.right(xd);
-    const float g00 = gelu_tab(u.k[4] * xe, T);
-    const float g01 = gelu_tab(u.k[3] * xe + u.k[5] * xr, T);
-    const float g10 = gelu_tab(u.k[1] * xe + u.k[7] * xd, T);
-    const float g11 = gelu_tab(u.k[0] * xe + u.k[2] * xr + u.k[6] * xd + u.k[8] * xdr, T);
-    const float g01l = L.left(g01), g11l = L.left(g11);
-    const float out = d.k[0] * g11lp + d.k[1] * g10p + d.k[2] * g11p
-                    + d.k[3] * g01l  + d.k[4] * g00  + d.k[5] * g01
-                    + d.k[6] * g11l  + d.k[7] * g10  + d.k[8] * g11;
-    if (L.live) y[base + i * S] = out;
-    g10p = g10; g11p = g11; g11lp = g11l; xr = xdr;
+  for (int k = 0; k < S + 2; ++k) {
+    if (k < S) {                                   // stage 1 of row k
+      ActRow& r = row[k & 1];
+      const float xe = xv[k], xd = xv[k + 1];
+      xr1 = L.right_mask(xr1);                     // (requested one row ago)
+      r.U[0] = u.k[4] * xe;
+      r.U[1] = u.k[3] * xe + u.k[5] * xr0;
+      r.U[2] = u.k[1] * xe + u.k[7] * xd;
+      r.U[3] = u.k[0] * xe + u.k[2] * xr0 + u.k[6] * xd + u.k[8] * xr1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) act_lookup(r.U[q], T, r.t[q], r.c[q]);
+      xr0 = xr1;
+      xr1 = (k + 2 <= S) ? lane_right(xv[k + 2]) : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);             // keep the stages in this order: the scheduler would otherwise pull each
+    //                                                consumer back up to its request to save registers, and re-serialise
+    if (k >= 2) {                                  // stage 3 of row k - 2
+      const ActG& g = gg[k & 1];
+      const float g01l = L.left_mask(g.g01l), g11l = L.left_mask(g.g11l);      // (requested one row ago)
+      const float out = d.k[0] * g11lp + d.k[1] * g10p + d.k[2] * g11p
+                      + d.k[3] * g01l + d.k[4] * g.g00 + d.k[5] * g.g01
+                      + d.k[6] * g11l + d.k[7] * g.g10 + d.k[8] * g.g11;
+      if (live) y[base + (k - 2) * S] = out;
+      g10p = g.g10; g11p = g.g11; g11lp = g11l;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (k >= 1 && k <= S) {                        // stage 2 of row k - 1
+      const ActRow& r = row[(k - 1) & 1];
+      ActG& g = gg[(k - 1) & 1];
+      g.g00 = r.U[0] * act_cubic(r.c[0], r.t[0]);
+      g.g01 = r.U[1] * act_cubic(r.c[1], r.t[1]);
+      g.g10 = r.U[2] * act_cubic(r.c[2], r.t[2]);
+      g.g11 = r.U[3] * act_cubic(r.c[3], r.t[3]);
+      g.g01l = lane_left(g.g01);                   // unmasked: stage 3 applies the plane border
+      g.g11l = lane_left(g.g11);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -311,61 +372,97 @@ __global__ __launch_bounds__(256) void filt_act_fwd_n3(const float* __restrict__
 //   dG[2i+1,2j]   = d21 dD[i,j] + d01 dD[i+1,j]
 //   dG[2i+1,2j+1] = d22 dD[i,j] + d20 dD[i,j+1] + d02 dD[i+1,j] + d00 dD[i+1,j+1]
 //   dU = dG * gelu'(U);   dv[i,j] = sum_{a,b} u[a,b] dU[2i-a+1, 2j-b+1]
-template <int S>
+// Same three-stage pipeline as the forward: stage 1 = U, dG and the GELU' table requests of row k, stage 2 = dU and its
+// left-neighbour shuffles of row k - 1, stage 3 = the up filter's adjoint taps of row k - 2.
+struct ActRowB { float t[4], dG[4]; float4 c[4]; };
+struct ActGB { float dU00, dU01, dU10, dU11, dU01l, dU11l; };
+
+template <int S, bool FULL>
 __global__ __launch_bounds__(256) void filt_act_bwd_n3(const float* __restrict__ x, const float* __restrict__ dy,
                                                        float* __restrict__ dv, long planes, int C,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ res,
                                                        float* __restrict__ part, Taps3 u, Taps3 d) {
-  __shared__ float4 Tb[2 * kGeluPieces];
-  load_gelu_table(Tb, 0, 2 * kGeluPieces);
-  const float4* T = Tb;
+  __shared__ float4 Tb[kGeluPieces];                 // the GELU' pieces only
+  load_gelu_table(Tb, kGeluPieces, kGeluPieces);
   Lane<S> L(planes);
   const long b = L.plane / C; const int c = L.plane % C;
   const long base = L.plane * (long)S * S + L.col;
+  if (FULL && !L.live) return;            // a whole wave beyond the last plane (the grid is rounded up to 4 waves): wave-uniform
+  const bool live = FULL || L.live;
   float sc, sh;
-  if (L.live) plane_affine(stats, gamma, beta, b, c, sc, sh); else { sc = 1.f; sh = 0.f; }
+  if (live) plane_affine(stats, gamma, beta, b, c, sc, sh); else { sc = 1.f; sh = 0.f; }
   float mean = 0.f, rstd = 1.f;
-  if (part && L.live) { mean = stats[2 * b]; rstd = stats[2 * b + 1]; }
-  float xv[S + 1], gv[S + 1];
+  if (part && live) { mean = stats[2 * b]; rstd = stats[2 * b + 1]; }
+  float xv[S + 2], gv[S + 2];
   float a1 = 0.f, a2 = 0.f;                         // GroupNorm-backward plane sums: sum dv*xhat, sum dv
   float hx[S];                                      // xhat of the raw input (only needed for the partials)
 #pragma unroll
   for (int i = 0; i < S; ++i) {
-    const float h = L.live ? x[base + i * S] : 0.f;
-    float v = h * sc + sh;
-    if (res && L.live) v += res[base + i * S];
-    xv[i] = L.live ? v : 0.f;
+    const float h = live ? x[base + i * S] : 0.f;
+    xv[i] = live ? fmaf(h, sc, sh) : 0.f;
     hx[i] = (h - mean) * rstd;
-    gv[i] = L.live ? dy[base + i * S] : 0.f;
+    gv[i] = live ? dy[base + i * S] : 0.f;
   }
-  xv[S] = 0.f; gv[S] = 0.f;
-  float u10p = 0.f, u11p = 0.f, u11lp = 0.f;       // dU on the odd row of the previous input row
-  float xr = L.right(xv[0]), gr = L.right(gv[0]);
+  if (res) {                                       // ONE uniform branch around all residual loads
 #pragma unroll
-  for (int i = 0; i < S; ++i) {
-    const float xe = xv[i], xd = xv[i + 1], ge = gv[i], gd = gv[i + 1];
-    const float xdr = L.right(xd), gdr = L.right(gd);
-    const float U00 = u.k[4] * xe;
-    const float U01 = u.k[3] * xe + u.k[5] * xr;
-    const float U10 = u.k[1] * xe + u.k[7] * xd;
-    const float U11 = u.k[0] * xe + u.k[2] * xr + u.k[6] * xd + u.k[8] * xdr;
-    const float dU00 = (d.k[4] * ge) * gelu_grad_tab(U00, T);
-    const float dU01 = (d.k[5] * ge + d.k[3] * gr) * gelu_grad_tab(U01, T);
-    const float dU10 = (d.k[7] * ge + d.k[1] * gd) * gelu_grad_tab(U10, T);
-    const float dU11 = (d.k[8] * ge + d.k[6] * gr + d.k[2] * gd + d.k[0] * gdr) * gelu_grad_tab(U11, T);
-    const float dU01l = L.left(dU01), dU11l = L.left(dU11);
-    const float out = u.k[0] * dU11 + u.k[1] * dU10 + u.k[2] * dU11l
-                    + u.k[3] * dU01 + u.k[4] * dU00 + u.k[5] * dU01l
-                    + u.k[6] * u11p + u.k[7] * u10p + u.k[8] * u11lp;
-    if (L.live) dv[base + i * S] = out;
-    a1 += out * hx[i]; a2 += out;
-    u10p = dU10; u11p = dU11; u11lp = dU11l; xr = xdr; gr = gdr;
+    for (int i = 0; i < S; ++i) xv[i] += live ? res[base + i * S] : 0.f;
+  }
+  xv[S] = 0.f; gv[S] = 0.f; xv[S + 1] = 0.f; gv[S + 1] = 0.f;
+  ActRowB row[2];
+  ActGB gg[2];
+  float u10p = 0.f, u11p = 0.f, u11lp = 0.f;       // dU on the odd row of the previous input row
+  float xr0 = L.right(xv[0]), xr1 = lane_right(xv[1]), gr0 = L.right(gv[0]), gr1 = lane_right(gv[1]);   // (xr1, gr1 unmasked)
+#pragma unroll
+  for (int k = 0; k < S + 2; ++k) {
+    if (k < S) {                                   // stage 1 of row k
+      ActRowB& r = row[k & 1];
+      const float xe = xv[k], xd = xv[k + 1], ge = gv[k], gd = gv[k + 1];
+      xr1 = L.right_mask(xr1); gr1 = L.right_mask(gr1);                       // (requested one row ago)
+      const float U00 = u.k[4] * xe;
+      const float U01 = u.k[3] * xe + u.k[5] * xr0;
+      const float U10 = u.k[1] * xe + u.k[7] * xd;
+      const float U11 = u.k[0] * xe + u.k[2] * xr0 + u.k[6] * xd + u.k[8] * xr1;
+      act_lookup(U00, Tb, r.t[0], r.c[0]);
+      act_lookup(U01, Tb, r.t[1], r.c[1]);
+      act_lookup(U10, Tb, r.t[2], r.c[2]);
+      act_lookup(U11, Tb, r.t[3], r.c[3]);
+      r.dG[0] = d.k[4] * ge;
+      r.dG[1] = d.k[5] * ge + d.k[3] * gr0;
+      r.dG[2] = d.k[7] * ge + d.k[1] * gd;
+      r.dG[3] = d.k[8] * ge + d.k[6] * gr0 + d.k[2] * gd + d.k[0] * gr1;
+      xr0 = xr1; gr0 = gr1;
+      xr1 = (k + 2 <= S) ? lane_right(xv[k + 2]) : 0.f;
+      gr1 = (k + 2 <= S) ? lane_right(gv[k + 2]) : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (k >= 2) {                                  // stage 3 of row k - 2
+      const ActGB& g = gg[k & 1];
+      const float dU01l = L.left_mask(g.dU01l), dU11l = L.left_mask(g.dU11l);   // (requested one row ago)
+      const float out = u.k[0] * g.dU11 + u.k[1] * g.dU10 + u.k[2] * dU11l
+                      + u.k[3] * g.dU01 + u.k[4] * g.dU00 + u.k[5] * dU01l
+                      + u.k[6] * u11p + u.k[7] * u10p + u.k[8] * u11lp;
+      if (live) dv[base + (k - 2) * S] = out;
+      a1 += out * hx[k - 2]; a2 += out;
+      u10p = g.dU10; u11p = g.dU11; u11lp = dU11l;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (k >= 1 && k <= S) {                        // stage 2 of row k - 1
+      const ActRowB& r = row[(k - 1) & 1];
+      ActGB& g = gg[(k - 1) & 1];
+      g.dU00 = r.dG[0] * act_cubic(r.c[0], r.t[0]);
+      g.dU01 = r.dG[1] * act_cubic(r.c[1], r.t[1]);
+      g.dU10 = r.dG[2] * act_cubic(r.c[2], r.t[2]);
+      g.dU11 = r.dG[3] * act_cubic(r.c[3], r.t[3]);
+      g.dU01l = lane_left(g.dU01);                 // unmasked: stage 3 applies the plane border
+      g.dU11l = lane_left(g.dU11);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (part) {                                       // reduce over the S lanes that share the plane (fixed butterfly)
 #pragma unroll
     for (int o = S / 2; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, kWave); a2 += __shfl_xor(a2, o, kWave); }
-    if (L.live && L.col == 0) { part[(2 * b) * C + c] = a1; part[(2 * b + 1) * C + c] = a2; }
+    if (live && L.col == 0) { part[(2 * b) * C + c] = a1; part[(2 * b + 1) * C + c] = a2; }
   }
 }
 
@@ -383,13 +480,17 @@ static inline Taps3 load_taps3(const float* k, bool rot180 = false) {
 }
 
 
+// (`planes` must be in scope: FULL = no dead lanes in the launch)
+#define AFD_DISPATCH_SF(S_, KERNEL, GRID_ARGS, ...)                                                      \
+  if (planes % (64 / (S_)) == 0) hipLaunchKernelGGL((KERNEL<S_, true>), GRID_ARGS, __VA_ARGS__);          \
+  else hipLaunchKernelGGL((KERNEL<S_, false>), GRID_ARGS, __VA_ARGS__)
 #define AFD_DISPATCH_S(S_, KERNEL, GRID_ARGS, ...)                                          \
   switch (S_) {                                                                              \
-    case 4:  hipLaunchKernelGGL(KERNEL<4>,  GRID_ARGS, __VA_ARGS__); break;                  \
-    case 8:  hipLaunchKernelGGL(KERNEL<8>,  GRID_ARGS, __VA_ARGS__); break;                  \
-    case 16: hipLaunchKernelGGL(KERNEL<16>, GRID_ARGS, __VA_ARGS__); break;                  \
-    case 32: hipLaunchKernelGGL(KERNEL<32>, GRID_ARGS, __VA_ARGS__); break;                  \
-    default: hipLaunchKernelGGL(KERNEL<64>, GRID_ARGS, __VA_ARGS__); break;                  \
+    case 4:  AFD_DISPATCH_SF(4, KERNEL, GRID_ARGS, __VA_ARGS__); break;                      \
+    case 8:  AFD_DISPATCH_SF(8, KERNEL, GRID_ARGS, __VA_ARGS__); break;                      \
+    case 16: AFD_DISPATCH_SF(16, KERNEL, GRID_ARGS, __VA_ARGS__); break;                     \
+    case 32: AFD_DISPATCH_SF(32, KERNEL, GRID_ARGS, __VA_ARGS__); break;                     \
+    default: AFD_DISPATCH_SF(64, KERNEL, GRID_ARGS, __VA_ARGS__); break;                     \
   }
 
 static inline dim3 fast_grid(long planes, int S) {
