@@ -336,24 +336,17 @@ bool attn_mfma8_ok(int d, int L);
 void attn_mfma8_fwd(const float* qkv, float* o, float* lse, int B, int heads, int L, float sc, hipStream_t s);
 void attn_mfma8_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta,
                     int B, int heads, int L, float sc, hipStream_t s);
-bool attn_fused8_ok(int d, int L);
-void attn_fused8_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta,
-                     int B, int heads, int L, float sc, hipStream_t s);
 }
 static int g_attn_mfma_bwd_all = 1;   // (afd_debug_attn_rows(10) off / (11) on): the MFMA d = 8 backward also at L = 1024 -- with the K / V tiles
                                       // prefetched through registers it beats the all-VALU pair there too (1.31 vs 1.49 ms at B = 256)
-static int g_attn_fused = 0;     // one-pass fused backward for d = 8 (afd_debug_attn_rows(8) off / (9) on).  OFF: correct (tests run
-                                 // it) but, as compiled today, register- and latency-bound -- 305 vs 115 us at L = 256, 13x slower at L = 1024
-                                 // where it spills; the two-pass kernels stay the default until its LDS row traffic is hand-scheduled
 static int g_attn_rows = 0;      // tuning hook: 0 = default (MFMA path for d = 8 when L % 256 == 0); 1,2,4 force the
                                  // all-VALU kernels with that many rows per lane
 
 extern "C" {
 
 int afd_debug_attn_rows(int r) {
-  if (r == 8 || r == 9) { g_attn_fused = r - 8; return AFD_OK; }
-  if (r == 10 || r == 11) { g_attn_mfma_bwd_all = r - 10; return AFD_OK; }         // fused d = 8 backward off / on (default on)
-  AFD_REQUIRE(r == 0 || r == 1 || r == 2 || r == 4, "afd_debug_attn_rows: r must be 0, 1, 2, 4 (rows per lane of the VALU kernels) or 8 / 9");
+  if (r == 10 || r == 11) { g_attn_mfma_bwd_all = r - 10; return AFD_OK; }         // MFMA d = 8 backward at L = 1024 off / on (default on)
+  AFD_REQUIRE(r == 0 || r == 1 || r == 2 || r == 4, "afd_debug_attn_rows: r must be 0, 1, 2, 4 (rows per lane of the VALU kernels), 10 or 11");
   g_attn_rows = r;
   return AFD_OK;
 }
@@ -390,10 +383,6 @@ int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float
   AFD_REQUIRE(B <= 65535 && heads <= 65535, "afd_attn_bwd: grid too large");
   hipStream_t s = as_stream(st);
   const float sc = 1.0f / sqrtf((float)d);
-  if (g_attn_rows == 0 && g_attn_fused && attn_fused8_ok(d, L)) {   // one pass: S, dP, exp and dS computed once
-    attn_fused8_bwd(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s);
-    return check_launch("afd_attn_bwd");
-  }
   if (g_attn_rows == 0 && attn_mfma8_ok(d, L) && (L < 1024 || g_attn_mfma_bwd_all)) {
     attn_mfma8_bwd(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s);
     return check_launch("afd_attn_bwd");

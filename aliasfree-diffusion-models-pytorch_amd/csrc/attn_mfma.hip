@@ -2,8 +2,7 @@
 // the two d-contractions of every pass on the fp32 matrix cores.
 //
 // S^T = K Q^T (and dP^T = V dO^T) are matrix-core products over d = 8 -- at fp32 accuracy on the bf16 path (three
-// v_mfma_f32_32x32x16_bf16 per 32x32 tile on exact three-piece splits of the operands, see split3 below; the one-pass
-// backward still uses four v_mfma_f32_32x32x2_f32).  Their accumulator layout -- lane = query column (l & 31), the 16 registers = 16 of the 32 keys, the other 16 in
+// v_mfma_f32_32x32x16_bf16 per 32x32 tile on exact three-piece splits of the operands, see split3 below).  Their accumulator layout -- lane = query column (l & 31), the 16 registers = 16 of the 32 keys, the other 16 in
 // lane ^ 32 -- is kept for everything that follows: the online softmax is a max over registers plus one
 // cross-half exchange, and the rank-8 products (P V, dS K, P^T dO, dS^T Q) are vector FMAs against LDS rows
 // that both tiles of a wave share.  Compared with the all-VALU kernels this removes 8 of 21 (forward),
@@ -382,164 +381,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma8(const float* __rest
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// fused backward (dQ, dK, dV in ONE kernel; S, dP, the exponentials and dS are computed once instead of twice).
-// Workgroup = one (batch, head); wave w owns queries [128 w, 128 w + 128) as 4 tiles of 32.  The workgroup makes four
-// passes (one query tile per wave per pass: the tile's Q / dO fragments, lse, delta and its dQ accumulators are the
-// only per-tile state, all in registers) and in each pass walks the keys in blocks of 32.  Per (key block, tile):
-// S^T and dP^T on the MFMA (lane = query, registers = keys), P and dS in that layout, dQ += dS K in-lane.
-// dK / dV need the sum over QUERIES, i.e. over the lane index: the P and dS tiles go through a wave-private LDS image
-// (4 ds_write_b128 + 16 ds_read_b32 each, no barrier) and come back with lane = key, where dV += P^T dO and
-// dK += dS^T Q are in-lane rank-8 updates against broadcast LDS rows.  Each key block ends with a fixed-order sum of
-// the waves' partials; passes 1..3 add to what the earlier passes wrote (fixed order: deterministic, no atomics).
-// ------------------------------------------------------------------------------------------------
-constexpr int kTS = 36;                              // row stride of the transposition images (conflict-free b128 writes)
-constexpr int kFusedWaveFloats = 2 * 32 * kTS + 2 * 32 * kD;
-
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_fused8(const float* __restrict__ qkv, const float* __restrict__ o,
-                                                            const float* __restrict__ d_o, const float* __restrict__ lse,
-                                                            float* __restrict__ dqkv, float* __restrict__ delta_out,
-                                                            int heads, float scale) {
-  constexpr int L = 128 * NW, NT = 64 * NW;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Kd = smem;                                  // [8][32]  K block, d-major (A fragments of S^T)
-  float* Vd = Kd + kD * 32;                          // [8][32]  V block, d-major (A fragments of dP^T)
-  float* Kr = Vd + kD * 32;                          // [32][8]  K rows (dQ updates)
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-  float* Pimg = Kr + 32 * kD + wv * kFusedWaveFloats;  // wave-private: [32 q][kTS] P tile
-  float* Dimg = Pimg + 32 * kTS;                     //               [32 q][kTS] dS tile
-  float* Qr = Dimg + 32 * kTS;                       //               [32 q][8] raw Q rows of the current tile
-  float* Gr = Qr + 32 * kD;                          //               [32 q][8] dO rows
-  const int b = blockIdx.y, h = blockIdx.x, C = heads * kD;
-  const float* qp = qkv + ((long)b * 3 * C + h * kD) * L;
-  const float* kp = qp + (long)C * L;
-  const float* vp = kp + (long)C * L;
-  const long ob = ((long)b * C + h * kD) * L;
-
-#pragma unroll 1
-  for (int pass = 0; pass < 4; ++pass) {
-    const int qi = wv * 128 + pass * 32 + l31;        // this lane's query in the pass's tile
-    float bq[4], bg[4];
-    float dpart = 0.f;
-    __syncthreads();                                  // (the previous pass's reducers are done with the image areas)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int d = 2 * s + half;
-      const float qv = qp[(long)d * L + qi], gv = d_o[ob + (long)d * L + qi];
-      bq[s] = qv * (scale * kLog2e);
-      bg[s] = gv;
-      dpart = fmaf(gv, o[ob + (long)d * L + qi], dpart);
-      Qr[l31 * kD + d] = qv;
-      Gr[l31 * kD + d] = gv;
-    }
-    const float dlt = dpart + xhalf(dpart);
-    const float lsq = lse[((long)b * heads + h) * L + qi] * kLog2e;
-    if (half == 0) delta_out[((long)b * heads + h) * L + qi] = dlt;
-    f2 dq[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dq[i] = (f2){0.f, 0.f};
-
-#pragma unroll 1
-    for (int k0 = 0; k0 < L; k0 += 32) {
-      __syncthreads();                                // K / V block and the partial-sum areas are free again
-      for (int i = threadIdx.x; i < 2 * kD * 32; i += NT) {
-        const int which = i >> 8, e = i & 255, d = e >> 5, kk = e & 31;
-        const float v = (which ? vp : kp)[(long)d * L + k0 + kk];
-        if (which) Vd[d * 32 + kk] = v; else { Kd[d * 32 + kk] = v; Kr[kk * kD + d] = v; }
-      }
-      __syncthreads();
-      // the tile's Q / dO rows never change inside a pass, so their loads are invariant in this loop -- and hoisting the
-      // 256 values per lane out of it costs 256 registers: launder the base pointers once per key block
-      const float* Qk = Qr; const float* Gk = Gr;
-      asm volatile("" : "+v"(Qk), "+v"(Gk));
-      f32x16 sc, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        sc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kd[(2 * s + half) * 32 + l31], bq[s], sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vd[(2 * s + half) * 32 + l31], bg[s], dp, 0, 0, 0);
-      }
-      // lane = query: P, dS, dQ += dS K; the tiles leave for the transposition images 4 keys at a time
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float pv[4], dv4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = 4 * g + i;
-          f2 kr[4];
-          load_row8(Kr + acc_row(r, half) * kD, kr);
-          const float p = __builtin_amdgcn_exp2f(sc[r] - lsq);
-          const float ds = p * (dp[r] - dlt);
-          axpy8(dq, ds, kr);
-          pv[i] = p; dv4[i] = ds;
-        }
-        *reinterpret_cast<float4*>(Pimg + l31 * kTS + 8 * g + 4 * half) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-        *reinterpret_cast<float4*>(Dimg + l31 * kTS + 8 * g + 4 * half) = make_float4(dv4[0], dv4[1], dv4[2], dv4[3]);
-        __builtin_amdgcn_sched_barrier(0);              // 4 keys at a time: front-loading all 16 LDS rows spills
-      }
-      // lane = key (l31), this half takes queries 16 half .. 16 half + 15 of the tile
-      f2 dkp[4], dvp[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { dkp[i] = (f2){0.f, 0.f}; dvp[i] = (f2){0.f, 0.f}; }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = 16 * half + r;
-        const float p = Pimg[q * kTS + l31], ds = Dimg[q * kTS + l31];
-        f2 grow[4], qrow[4];
-        load_row8(Gk + q * kD, grow);
-        load_row8(Qk + q * kD, qrow);
-        axpy8(dvp, p, grow);
-        axpy8(dkp, ds, qrow);
-        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-      // this wave's partial dK / dV rows of the block -> its own image area [32 keys][16], then a fixed-order sum
-#pragma unroll
-      for (int d = 0; d < kD; ++d) {
-        const float mk = dkp[d >> 1][d & 1], mv = dvp[d >> 1][d & 1];
-        const float tk = mk + xhalf(mk), tv = mv + xhalf(mv);
-        if (half == 0) { Pimg[l31 * 16 + d] = tk; Pimg[l31 * 16 + 8 + d] = tv; }
-      }
-      __syncthreads();
-      for (int t = threadIdx.x; t < 32 * 16; t += NT) {
-        const int kk = t & 31, c = t >> 5;            // consecutive threads = consecutive keys: 128-B stores
-        float sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) sum += (Kr + 32 * kD + w * kFusedWaveFloats)[kk * 16 + c];
-        const int chan = (c < 8) ? (C + h * kD + c) : (2 * C + h * kD + (c - 8));
-        float* dst = dqkv + ((long)b * 3 * C + chan) * L + k0 + kk;
-        const float val = (c < 8) ? sum * scale : sum;
-        *dst = pass ? *dst + val : val;                 // passes add in order: deterministic
-      }
-    }
-#pragma unroll
-    for (int d = 0; d < kD; ++d) {
-      const float mine = dq[d >> 1][d & 1];
-      const float t = mine + xhalf(mine);
-      if (half == 0) dqkv[((long)b * 3 * C + h * kD + d) * L + qi] = t * scale;
-    }
-  }
-}
-
-bool attn_fused8_ok(int d, int L) { return d == 8 && (L == 256 || L == 512 || L == 1024); }
-template <int NW>
-static void attn_fused8_launch(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta,
-                               int B, int heads, float sc, hipStream_t s) {
-  const size_t lds = sizeof(float) * (3 * 32 * kD + (size_t)NW * kFusedWaveFloats);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused8<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((attn_bwd_fused8<NW>), dim3(heads, B), dim3(64 * NW), lds, s, qkv, o, d_o, lse, dqkv, delta, heads, sc);
-}
-void attn_fused8_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta,
-                     int B, int heads, int L, float sc, hipStream_t s) {
-  if (L == 256) attn_fused8_launch<2>(qkv, o, d_o, lse, dqkv, delta, B, heads, sc, s);
-  else if (L == 512) attn_fused8_launch<4>(qkv, o, d_o, lse, dqkv, delta, B, heads, sc, s);
-  else attn_fused8_launch<8>(qkv, o, d_o, lse, dqkv, delta, B, heads, sc, s);
-}
+// A one-pass backward (S, dP, the exponentials and dS computed once, P and dS transposed through wave-private LDS so that
+// dK / dV become in-lane sums) was built and measured in round 1: register-bound (the loop-invariant Q / dO rows take
+// ~250 registers, or spill), 2.7-13x slower than the two passes above.  It was removed in round 2; the numbers are in
+// DESIGN.md section 6.
 
 // host-side launchers used by attn.hip
 bool attn_mfma8_ok(int d, int L) { return d == 8 && L % 256 == 0; }

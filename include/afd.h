@@ -176,8 +176,7 @@ int afd_layernorm_c_bwd_params(const float* x, const float* dy, const float* sta
  * ddpm_utils.py:71 (nn.MultiheadAttention, batch_first, 4 heads).  qkv (B,3C,L): channel
  * n = {0:q,1:k,2:v}*C + head*d + j, token index contiguous (the NCHW image of in_proj's output).
  * o (B,C,L); lse (B,heads,L) saved for backward.  Never materialises the L x L scores. */
-/* tuning hook: force R rows per lane (1, 2, 4) for head dim 8; 0 = default; 8 / 9 = one-pass fused backward for
- * head dim 8 (L in {256, 512, 1024}) off / on (default off: measured slower than the two-pass kernels);
+/* tuning hook: force R rows per lane (1, 2, 4) of the all-vector kernels for head dim 8; 0 = default;
  * 10 / 11 = the MFMA two-pass backward for head dim 8 only below L = 1024 / at every L (default) */
 int afd_debug_attn_rows(int rows);
 int afd_attn_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d, int L, afd_stream_t stream);

@@ -79,6 +79,55 @@ def test_filt_fast_paths_vs_oracle(A, S):
         check(f"F2/F3/F4 fast path {name} bwd vs oracle", dxg.cpu(), dxo, TOL, f"S={S}")
 
 
+@pytest.mark.parametrize("S", [4, 8, 16, 32])
+def test_filt_fast_paths_do_not_write_outside_their_tensors(A, S):
+    """Guard bands around every output of the F2 / F3 / F4 fast paths.  The launches are rounded up to 4 waves per
+    workgroup, so plane counts that fill whole waves (the no-dead-lane kernel variants) but not whole workgroups leave
+    waves beyond the last plane: they must exit, not compute on (and store to) memory past the tensor."""
+    afdm, ops, dev = A
+    L = afdm.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    ppw = 64 // S
+    tk = ops.Taps(afdm.circularLowpassKernel(math.pi / 2, 3, 2))
+    for planes in (ppw, 3 * ppw, 5 * ppw, 3 * ppw + 1):                 # 1, 3, 5 waves; and one partly dead wave
+        B, C = 1, planes
+        n, n_hi = planes * S * S, planes * 4 * S * S
+        pad = 4096
+        x = torch.randn(B, C, S, S, device=dev)
+        x_hi = torch.randn(B, C, 2 * S, 2 * S, device=dev)
+        st = torch.zeros(B, 2, device=dev); st[:, 1] = 1
+        g, be = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+
+        def guarded(numel):
+            buf = torch.full((numel + 2 * pad,), 7.25, device=dev)
+            return buf, buf[pad:pad + numel]
+
+        def intact(buf, numel, what):
+            assert bool((buf[:pad] == 7.25).all()) and bool((buf[pad + numel:] == 7.25).all()), (what, S, planes)
+
+        buf, y = guarded(n)
+        L.afd_filt_act_fwd(x.data_ptr(), y.data_ptr(), B, C, S, S, st.data_ptr(), g.data_ptr(), be.data_ptr(), None, tk.ptr, tk.ptr, 3, None, s)
+        intact(buf, n, "filt_act_fwd")
+        buf, dv = guarded(n)
+        pbuf, part = guarded(B * C * 2)
+        L.afd_filt_act_bwd(x.data_ptr(), x.data_ptr(), dv.data_ptr(), B, C, S, S, st.data_ptr(), g.data_ptr(), be.data_ptr(), None, tk.ptr, tk.ptr, 3, None,
+                           part.data_ptr(), s)
+        intact(buf, n, "filt_act_bwd"); intact(pbuf, B * C * 2, "filt_act_bwd partials")
+        buf, up = guarded(n_hi)
+        L.afd_filt_up2_fwd(x.data_ptr(), up.data_ptr(), B, C, S, S, 0, 0, tk.ptr, 3, s)
+        intact(buf, n_hi, "up2_fwd")
+        buf, dn = guarded(n)
+        L.afd_filt_down2_fwd(x_hi.data_ptr(), dn.data_ptr(), B, C, 2 * S, 2 * S, 0, 0, tk.ptr, 3, s)
+        intact(buf, n, "down2_fwd")
+        buf, dx = guarded(n)
+        L.afd_filt_up2_bwd(x_hi.data_ptr(), dx.data_ptr(), B, C, S, S, 0, 0, tk.ptr, 3, s)
+        intact(buf, n, "up2_bwd")
+        buf, dxh = guarded(n_hi)
+        L.afd_filt_down2_bwd(x.data_ptr(), dxh.data_ptr(), B, C, 2 * S, 2 * S, 0, 0, tk.ptr, 3, s)
+        intact(buf, n_hi, "down2_bwd")
+    torch.cuda.synchronize()
+
+
 def test_filt_properties_full_size(A):
     """BASELINE size (B=256, C=64, 32x32): linearity, adjointness, DC gain -- size-independent checks."""
     afdm, ops, dev = A
@@ -385,13 +434,14 @@ def test_layernorm_c(A, shape):
 
 @pytest.mark.parametrize("cfg", [(2, 4, 8, 1024), (2, 4, 8, 256), (3, 2, 8, 512), (3, 4, 16, 256), (2, 4, 32, 64), (5, 4, 32, 16),
                                  (2, 4, 16, 64), (2, 2, 8, 100), (1, 4, 64, 48)])
-@pytest.mark.parametrize("fused", [True, False])
-def test_attention_core(A, cfg, fused):
+@pytest.mark.parametrize("rows", [0, 1])
+def test_attention_core(A, cfg, rows):
+    """rows = 0: the kernels the rule picks (MFMA passes at d = 8, L % 256 == 0); rows = 1: the all-vector kernels forced."""
     afdm, ops, dev = A
     B, heads, d, L = cfg
-    if fused and not (d == 8 and L in (256, 512, 1024)):
-        pytest.skip("the one-pass backward only exists for d = 8, L in {256, 512, 1024}")
-    afdm.lib().afd_debug_attn_rows(9 if fused else 8)
+    if rows and d != 8:
+        pytest.skip("the rows-per-lane hook only changes the d = 8 dispatch")
+    afdm.lib().afd_debug_attn_rows(rows)
     C = heads * d
     g = _g(L + d)
     qkv = torch.randn(B, 3 * C, L, 1, generator=g)
@@ -405,7 +455,7 @@ def test_attention_core(A, cfg, fused):
     qd = qkv.to(dev).requires_grad_(True)
     yd = ops.Attention.apply(qd, heads)
     (gd,) = torch.autograd.grad(yd, qd, dy.to(dev))
-    afdm.lib().afd_debug_attn_rows(8)
+    afdm.lib().afd_debug_attn_rows(0)
     check("F10 attention core fwd vs fp64", yd.detach().cpu(), yo.detach(), TOL, cfg)
     check("F10 attention core bwd vs fp64", gd.cpu(), go, TOL, cfg)
 
