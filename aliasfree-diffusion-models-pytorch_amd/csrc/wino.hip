@@ -684,11 +684,14 @@ void wgrad_wino(const float* __restrict__ x, const float* __restrict__ dy, float
 #pragma unroll
     for (int h = 0; h < 2; ++h) acc[xi][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifndef AFD_WGW_ABL
+#define AFD_WGW_ABL 0
+#endif
   if (cbeg < cend) fetch();
   for (int c = cbeg; c < cend; ++c) {
     __syncthreads();                                  // the previous chunk's transforms are done with Xs / Gs (first pass: the zero fill)
-    commit();
-    if (c + 1 < cend) fetch();                        // in flight during the multiplies
+    if (!(AFD_WGW_ABL & 8) || c == cbeg) commit();
+    if (c + 1 < cend && (!(AFD_WGW_ABL & 4))) fetch();                        // in flight during the multiplies
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -704,6 +707,10 @@ void wgrad_wino(const float* __restrict__ x, const float* __restrict__ dy, float
           d[a][0] = lo.x; d[a][1] = lo.y; d[a][2] = hi.x; d[a][3] = hi.y;
         }
         float w[4][4];
+        if (AFD_WGW_ABL & 1) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = d[i >> 2][i & 3];
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           w[0][j] = d[0][j] - d[2][j];
@@ -717,6 +724,7 @@ void wgrad_wino(const float* __restrict__ x, const float* __restrict__ dy, float
           v[4 * i + 1] = w[i][1] + w[i][2];
           v[4 * i + 2] = w[i][2] - w[i][1];
           v[4 * i + 3] = w[i][1] - w[i][3];
+        }
         }
       }
 #pragma unroll
@@ -733,7 +741,10 @@ void wgrad_wino(const float* __restrict__ x, const float* __restrict__ dy, float
         m[8] = amc;  m[9] = amc + bmd; m[10] = amc - bmd; m[11] = bmd;
         m[12] = cc;  m[13] = cc + d;   m[14] = cc - d;   m[15] = d;
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) acc[xi][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(m[xi], v[xi], acc[xi][h], 0, 0, 0);
+        for (int xi = 0; xi < 16; ++xi) {
+          if (AFD_WGW_ABL & 2) { asm volatile("" :: "v"(m[xi]), "v"(v[xi])); }
+          else acc[xi][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(m[xi], v[xi], acc[xi][h], 0, 0, 0);
+        }
       }
     }
   }
