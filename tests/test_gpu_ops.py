@@ -383,6 +383,40 @@ def test_pointwise_full_batch_matches_double_precision(A):
         assert rel_l2(dxd[i:i + 1].cpu(), dxi) < 5e-6
 
 
+@pytest.mark.parametrize("shape", [(32, 96, 32), (32, 32, 32), (64, 192, 16), (64, 64, 8), (128, 384, 8), (128, 128, 4), (32, 96, 16)],
+                         ids=lambda t: f"{t[0]}to{t[1]}_{t[2]}x{t[2]}")
+def test_linear_wgrad_full_batch_matches_double_precision(A, shape):
+    """Weight / bias gradients of the attention blocks' Linear layers (1x1 wgrad: pixel-split partial slabs + a fixed-order
+    slab sum) at B = 256 against fp64 on the whole batch, non-accumulating and accumulating; bit-identical between two
+    runs (no atomics)."""
+    afdm, ops, dev = A
+    L = afdm.lib()
+    K, N, S = shape
+    B = 256
+    g = _g(K + N + S)
+    x = torch.randn(B, K, S, S, generator=g)
+    dy = torch.randn(B, N, S, S, generator=g)
+    dw_ref = torch.einsum("bnp,bkp->nk", dy.double().reshape(B, N, -1), x.double().reshape(B, K, -1))
+    db_ref = dy.double().sum(dim=(0, 2, 3))
+    xd, dyd = x.to(dev), dy.to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(max(L.afd_conv_wgrad_workspace_bytes(B, K, N, S, S, 1) // 4, 1), device=dev)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((N, K), 3.0, device=dev); db = torch.full((N,), -2.0, device=dev)
+        L.afd_conv_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), B, K, N, S, S, 1, 0, ws.data_ptr(), s)
+        outs.append((dw.clone(), db.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    check("F10 Linear weight grads (B = 256) vs fp64", outs[0][0].cpu(), dw_ref, 5e-6, shape)
+    check("F10 Linear bias grads (B = 256) vs fp64", outs[0][1].cpu(), db_ref, 5e-6, shape)
+    dw = torch.full((N, K), 3.0, device=dev); db = torch.full((N,), -2.0, device=dev)
+    L.afd_conv_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), B, K, N, S, S, 1, 1, ws.data_ptr(), s)
+    assert rel_l2(dw.cpu() - 3.0, dw_ref) < 5e-6 and rel_l2(db.cpu() + 2.0, db_ref) < 5e-6
+    dw2 = torch.empty(N, K, device=dev)                                   # no bias pointer
+    L.afd_conv_wgrad(xd.data_ptr(), dyd.data_ptr(), dw2.data_ptr(), None, B, K, N, S, S, 1, 0, ws.data_ptr(), s)
+    assert torch.equal(dw2, outs[0][0])
+
+
 def test_conv_wgrad_full_batch_matches_double_precision(A):
     """BASELINE batch (256) for an encoder conv (32->32 @16x16, the 8-wave split-K plan): dw and db against fp64."""
     _, ops, dev = A
