@@ -799,7 +799,9 @@ int wino_plan(int B, int K, int N, int H, int W);
 bool wino_conv(const float* x, const float* w, const float* bias, const float* res, float* y, float* U, int B, int K, int N, int H,
                int W, int act, bool dgrad, bool weights_ready, hipStream_t s);
 void wino_set_mode(int m);
-void wino_weights_launch(const float* w, float* Uf, float* Ud, int Cin, int Cout, hipStream_t s);
+void wino_weights_launch(const float* w, float* Uf, float* Ud, int Cin, int Cout, int kinds, hipStream_t s);
+bool bf3_ok(int B, int K, int N, int H, int W);       // bf3.hip: the direct bf16x3 form of a 3x3 layer
+void bf3_set_mode(int m);
 void wino_weights_batched_launch(const afd_wino_desc* descs, const int* wg_desc, int n_wg, hipStream_t s);
 void wino_set_grid(int g);
 int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, int* cps, int* nchunks);
@@ -912,6 +914,7 @@ using namespace afd;
 extern "C" {
 
 int afd_debug_conv_path(int mode) {
+  if (mode >= 80 && mode <= 82) { bf3_set_mode(mode - 80); return AFD_OK; }   // direct bf16x3 3x3 kernel: 80 = by rule (default), 81 = off, 82 = wherever covered
   if (mode >= 8 && mode <= 10) { pw_set_mode(mode - 8); return AFD_OK; }     // 1x1 streaming kernel: 8 = by rule (default), 9 = off, 10 = forced
   if (mode >= 100000 && mode < 200000) { wino_set_grid(mode - 100000); return AFD_OK; }   // Winograd persistent grid size (0 = default)
   if (mode >= 96 && mode <= 98) { wgrad_wino_set_mode(mode - 96); return AFD_OK; }   // Winograd wgrad: 96 = by rule (default), 97 = off, 98 = whenever covered
@@ -961,12 +964,19 @@ int afd_conv_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, i
 size_t afd_conv3x3_wino_workspace_bytes(int B, int Cin, int Cout, int H, int W, int dgrad) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
   const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
-  return wino_plan(B, K, N, H, W) ? sizeof(float) * 16 * (size_t)Cin * Cout : 0;
+  // (the bf16x3 weight image needs 54 bytes per (cin, cout) pair, the Winograd one 64: one size serves both)
+  return (bf3_ok(B, K, N, H, W) || wino_plan(B, K, N, H, W)) ? sizeof(float) * 16 * (size_t)Cin * Cout : 0;
 }
 
-int afd_conv3x3_wino_weights(const float* w, float* u_fwd, float* u_dgrad, int Cin, int Cout, afd_stream_t st) {
+int afd_conv3x3_weight_kinds(int B, int Cin, int Cout, int H, int W) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  return (bf3_ok(B, Cin, Cout, H, W) ? 1 : 0) | (bf3_ok(B, Cout, Cin, H, W) ? 2 : 0);
+}
+
+int afd_conv3x3_wino_weights(const float* w, float* u_fwd, float* u_dgrad, int Cin, int Cout, int kinds, afd_stream_t st) {
   AFD_REQUIRE(w && (u_fwd || u_dgrad) && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, "afd_conv3x3_wino_weights: bad argument");
-  wino_weights_launch(w, u_fwd, u_dgrad, Cin, Cout, as_stream(st));
+  AFD_REQUIRE(kinds >= 0 && kinds <= 3 && (!(kinds & 3) || (Cin % 16 == 0 && Cout % 16 == 0)), "afd_conv3x3_wino_weights: bad kinds %d", kinds);
+  wino_weights_launch(w, u_fwd, u_dgrad, Cin, Cout, kinds, as_stream(st));
   return check_launch("afd_conv3x3_wino_weights");
 }
 

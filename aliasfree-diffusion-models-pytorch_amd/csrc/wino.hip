@@ -16,6 +16,7 @@
 //                  register arithmetic and the 2x2 results leave as float2 stores.
 #include <cstdlib>
 #include "common.h"
+#include "bf3_weights.h"
 
 namespace afd {
 
@@ -106,9 +107,14 @@ __global__ __launch_bounds__(256) void wino_weights(const float* __restrict__ w,
 }
 
 // every layer of a model in ONE launch: workgroup g works on layer wg_desc[g] (afd_wino_desc, include/afd.h)
+
 __global__ __launch_bounds__(256) void wino_weights_batched(const afd_wino_desc* __restrict__ descs, const int* __restrict__ wg_desc) {
   const afd_wino_desc d = descs[wg_desc[blockIdx.x]];
-  wino_weights_block(d.w, d.u_fwd, d.u_dgrad, d.Cin, d.Cout, (blockIdx.x - d.first_wg) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+  const int blk = (blockIdx.x - d.first_wg) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float* wf = (d.kinds & 1) ? nullptr : d.u_fwd; float* wd = (d.kinds & 2) ? nullptr : d.u_dgrad;
+  if (wf || wd) wino_weights_block(d.w, wf, wd, d.Cin, d.Cout, blk, lane);
+  void* bf = (d.kinds & 1) ? d.u_fwd : nullptr; void* bd = (d.kinds & 2) ? d.u_dgrad : nullptr;
+  if (bf || bd) bf3_weights_block(d.w, static_cast<__bf16*>(bf), static_cast<__bf16*>(bd), d.Cin, d.Cout, blk, lane);   // same wave-per-8x8-block decomposition
 }
 
 template <int GEO, int BN, int NT>
@@ -550,13 +556,24 @@ static void wino_launch_t(const float* x, const float* U, const float* bias, con
   hipLaunchKernelGGL((conv_wino<GEO, BN, NT>), dim3(grid), dim3(BN * NT / 8), lds, s, x, U, bias, res, y, B, K, N, act, items);
 }
 
+// bf3.hip: the direct bf16x3 form (takes the layers it covers ahead of the Winograd kernels)
+bool bf3_ok(int B, int K, int N, int H, int W);
+void bf3_weights_launch(const float* w, void* Wf, void* Wd, int Cin, int Cout, hipStream_t s);
+void bf3_conv(const float* x, const void* Wp, const float* bias, const float* res, float* y, int B, int K, int N, int S, int act,
+              hipStream_t s);
+
 // conv (dgrad = false: x (B,K,H,W), w (N,K,3,3)) or its input gradient (dgrad = true: x = dY (B,K=Cout,H,W), w (K,N,3,3))
 bool wino_conv(const float* x, const float* w, const float* bias, const float* res, float* y, float* U, int B, int K, int N, int H,
                int W, int act, bool dgrad, bool weights_ready, hipStream_t s) {
+  const int Cin = dgrad ? N : K, Cout = dgrad ? K : N;
+  if (U && bf3_ok(B, K, N, H, W)) {                 // the workspace then holds the bf16x3 weight image of this pass
+    if (!weights_ready) bf3_weights_launch(w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout, s);
+    bf3_conv(x, U, bias, res, y, B, K, N, W, act, s);
+    return true;
+  }
   const int plan = wino_plan(B, K, N, H, W);
   if (!plan || !U) return false;
   const int bn = plan >> 8, nt = plan & 255;
-  const int Cin = dgrad ? N : K, Cout = dgrad ? K : N;
   if (plan == 1) {
     if (!weights_ready)
       hipLaunchKernelGGL(wino_weights, dim3((unsigned)((K * N / 64 + 3) / 4)), dim3(256), 0, s, w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout);
@@ -831,9 +848,12 @@ int wgrad_wino(const float* x, const float* dy, float* part, int B, int Cin, int
   return splits;
 }
 
-// both (or either) transformed-weight images of a layer in one launch
-void wino_weights_launch(const float* w, float* Uf, float* Ud, int Cin, int Cout, hipStream_t s) {
-  hipLaunchKernelGGL(wino_weights, dim3((unsigned)((Cin * Cout / 64 + 3) / 4)), dim3(256), 0, s, w, Uf, Ud, Cin, Cout);
+// both (or either) transformed-weight images of a layer; kinds bit 0 / 1: the forward / dgrad image is the bf16x3 one
+void wino_weights_launch(const float* w, float* Uf, float* Ud, int Cin, int Cout, int kinds, hipStream_t s) {
+  float* wf = (kinds & 1) ? nullptr : Uf; float* wd = (kinds & 2) ? nullptr : Ud;
+  if (wf || wd) hipLaunchKernelGGL(wino_weights, dim3((unsigned)((Cin * Cout / 64 + 3) / 4)), dim3(256), 0, s, w, wf, wd, Cin, Cout);
+  void* bf = (kinds & 1) ? Uf : nullptr; void* bd = (kinds & 2) ? Ud : nullptr;
+  if (bf || bd) bf3_weights_launch(w, bf, bd, Cin, Cout, s);
 }
 
 void wino_weights_batched_launch(const afd_wino_desc* descs, const int* wg_desc, int n_wg, hipStream_t s) {

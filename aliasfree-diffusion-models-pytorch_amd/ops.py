@@ -375,17 +375,19 @@ class _WinoWeights:
     active_plan = None        # WinoStepPlan whose buffers were filled at the start of the current step
 
     @classmethod
-    def get(cls, w, nbytes, dgrad):
+    def get(cls, w, nbytes, dgrad, kinds=0):
         plan = cls.active_plan
         if plan is not None:
-            u = plan.lookup(w, nbytes, dgrad)
+            u = plan.lookup(w, nbytes, dgrad, kinds)
             if u is not None:
                 return u, 1
         if cls.recording is not None:
-            cls.recording.setdefault(id(w), [w, 0, 0])[1 + dgrad] = nbytes
+            rec = cls.recording.setdefault(id(w), [w, 0, 0, 0])
+            rec[1 + dgrad] = nbytes
+            rec[3] = kinds
         capturing = torch.cuda.is_current_stream_capturing()
         key = (id(w), dgrad, _stream())
-        stamp = (w._version, cls.epoch, w.data_ptr(), nbytes)
+        stamp = (w._version, cls.epoch, w.data_ptr(), nbytes, kinds >> dgrad & 1)     # (the image's form follows the batch size)
         if not capturing:
             hit = cls.store.get(key)
             if hit is not None and hit[0]() is w and hit[2] == stamp:
@@ -416,29 +418,29 @@ class WinoStepPlan:
         dev = reqs[0][0].device
         self.buf = torch.empty(sum(r[1] + r[2] for r in reqs) // 4, device=dev, dtype=torch.float32)
         self.map, descs, wg, off = {}, b"", [], 0
-        for i, (w, nf, nd) in enumerate(reqs):
+        for i, (w, nf, nd, kinds) in enumerate(reqs):
             Cout, Cin = w.shape[0], w.shape[1]
             uf = self.buf[off:off + nf // 4] if nf else None
             off += nf // 4
             ud = self.buf[off:off + nd // 4] if nd else None
             off += nd // 4
-            self.map[id(w)] = (weakref.ref(w), w.data_ptr(), uf, ud)
+            self.map[id(w)] = (weakref.ref(w), w.data_ptr(), uf, ud, kinds)
             n_wg = (Cin * Cout // 64 + 3) // 4
-            descs += struct.pack("<QQQiiii", w.data_ptr(), uf.data_ptr() if nf else 0, ud.data_ptr() if nd else 0, Cin, Cout, len(wg), 0)
+            descs += struct.pack("<QQQiiii", w.data_ptr(), uf.data_ptr() if nf else 0, ud.data_ptr() if nd else 0, Cin, Cout, len(wg), kinds)
             wg += [i] * n_wg
         self.n_wg = len(wg)
         self.descs = torch.frombuffer(bytearray(descs), dtype=torch.uint8).to(dev)
         self.wg = torch.tensor(wg, dtype=torch.int32).to(dev)
 
     def valid(self):
-        return self.ok and all(r() is not None and r().data_ptr() == ptr for (r, ptr, _, _) in self.map.values())
+        return self.ok and all(r() is not None and r().data_ptr() == ptr for (r, ptr, _, _, _) in self.map.values())
 
     def launch(self):
         lib().afd_conv3x3_wino_weights_batched(_p(self.descs), _p(self.wg), self.n_wg, _stream())
 
-    def lookup(self, w, nbytes, dgrad):
+    def lookup(self, w, nbytes, dgrad, kinds=0):
         e = self.map.get(id(w))
-        if e is None or e[0]() is not w:
+        if e is None or e[0]() is not w or (e[4] ^ kinds) >> dgrad & 1:       # (another batch size may want the other form)
             return None
         u = e[3] if dgrad else e[2]
         return u if (u is not None and u.numel() * 4 == nbytes) else None
@@ -458,11 +460,12 @@ def _conv_fwd(x, w, bias, res, y, B, Cin, Cout, H, W, ks, act, want_dgrad=False)
     nd = L.afd_conv3x3_wino_workspace_bytes(B, Cin, Cout, H, W, 1) if (ks == 3 and want_dgrad) else 0
     ud = None
     if nb:
-        u, ready = _WinoWeights.get(w, nb, 0)
+        kinds = L.afd_conv3x3_weight_kinds(B, Cin, Cout, H, W)     # which passes run the direct bf16x3 form (their image differs)
+        u, ready = _WinoWeights.get(w, nb, 0, kinds)
         if nd:
-            ud, dready = _WinoWeights.get(w, nd, 1)
+            ud, dready = _WinoWeights.get(w, nd, 1, kinds)
             if not (ready and dready):
-                L.afd_conv3x3_wino_weights(_p(w), _p(u), _p(ud), Cin, Cout, _stream())
+                L.afd_conv3x3_wino_weights(_p(w), _p(u), _p(ud), Cin, Cout, kinds, _stream())
                 ready = 1
         L.afd_conv3x3_wino_fwd(_p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Cout, H, W, act, _p(u), ready, _stream())
     else:
@@ -507,7 +510,7 @@ class Conv(_Fn):
                 if ctx.u_dgrad is not None:            # produced together with the forward image
                     u, ready = ctx.u_dgrad, 1
                 else:
-                    u, ready = _WinoWeights.get(w, nb, 1)
+                    u, ready = _WinoWeights.get(w, nb, 1, L.afd_conv3x3_weight_kinds(B, Cin, Cout, H, W))
                 L.afd_conv3x3_wino_dgrad(_p(dy), _p(w), _p(dx), _p(dfork), B, Cin, Cout, H, W, _p(u), ready, _stream())
             else:
                 L.afd_conv_dgrad(_p(dy), _p(w), _p(dx), B, Cin, Cout, H, W, ks, _stream())

@@ -137,7 +137,14 @@ size_t afd_conv3x3_wino_workspace_bytes(int B, int Cin, int Cout, int H, int W, 
 /* the transformed weights of both passes (either pointer may be NULL) in ONE launch: the dgrad image is the forward
  * image with permuted transform indices.  Buffers of 16*Cin*Cout floats each; afterwards call the entry points below
  * with weights_ready = 1. */
-int afd_conv3x3_wino_weights(const float* w, float* u_fwd, float* u_dgrad, int Cin, int Cout, afd_stream_t stream);
+int afd_conv3x3_wino_weights(const float* w, float* u_fwd, float* u_dgrad, int Cin, int Cout, int kinds, afd_stream_t stream);
+/* Some layers run a DIRECT form on the bf16 matrix cores at fp32 accuracy instead (csrc/bf3.hip: every operand split
+ * exactly into three bf16 pieces, six cross terms per product; chosen by the library per pass from the shape): their
+ * workspace holds the split weights (54 bytes per (cin, cout) pair -- the same buffer size serves both forms).
+ * kinds: bit 0 / bit 1 set = the forward / the dgrad image of this layer is the bf16x3 one; pass it to the two weight
+ * entry points (afd_wino_desc.kinds for the batched one).  afd_debug_conv_path 80 / 81 / 82 = that form by the measured
+ * rule (default) / never / wherever the shape is covered. */
+int afd_conv3x3_weight_kinds(int B, int Cin, int Cout, int H, int W);
 /* ... and of EVERY layer of a model in one launch (a train step transforms ~30 weight tensors; one launch instead of
  * 30 takes them off the critical path).  descs (DEVICE array): one entry per layer; wg_desc (DEVICE, n_wg ints): the
  * layer each 256-thread workgroup works on -- layer i owns workgroups [first_wg, first_wg + ceil(Cin*Cout/256)). */
@@ -145,7 +152,7 @@ typedef struct afd_wino_desc {
   const float* w;        /* (Cout,Cin,3,3) */
   float* u_fwd;          /* 16*Cin*Cout floats or NULL */
   float* u_dgrad;        /* 16*Cin*Cout floats or NULL */
-  int Cin, Cout, first_wg, reserved;
+  int Cin, Cout, first_wg, kinds;   /* kinds: afd_conv3x3_weight_kinds of the layer */
 } afd_wino_desc;
 int afd_conv3x3_wino_weights_batched(const afd_wino_desc* descs, const int* wg_desc, int n_wg, afd_stream_t stream);
 int afd_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,

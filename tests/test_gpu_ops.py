@@ -252,14 +252,17 @@ CONV_CASES = [
     (3, 8, 96, 16, 16, 3, False, False),      # Winograd: one chunk, three 32-channel blocks
     (6, 64, 96, 4, 4, 3, True, True),         # small-map split-K Winograd: 4 images per group, ragged last group, epilogue
     (3, 128, 32, 8, 8, 3, False, False),      # small-map split-K Winograd: one 8x8 image per group
+    (3, 32, 128, 32, 32, 3, True, True),      # direct bf16x3 form: four 32-channel blocks per workgroup, epilogue
+    (5, 256, 256, 8, 8, 3, False, False),     # direct bf16x3 form: 8 chunks, two images per tile, ragged last tile
+    (2, 96, 160, 16, 16, 3, False, False),    # direct bf16x3 form: 3 chunks, five single 32-channel blocks
 ]
 
 
-@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "winosk", "nowino", "wgwino", "nowgwino"])
+@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "bf3", "nobf3", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "winosk", "nowino", "wgwino", "nowgwino"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[5]}" for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(A, case, path):
     afdm, ops, dev = A
-    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10,
+    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10, "bf3": 82, "nobf3": 81,
                                         "wino64x64": 66, "wino32x64": 67, "wino64x32": 68, "wino32x32": 69, "winosk": 70, "nowino": 65, "wgwino": 98, "nowgwino": 97}[path])
     try:
         _conv_case(ops, dev, case)
@@ -267,6 +270,7 @@ def test_conv_fwd_dgrad_wgrad(A, case, path):
         afdm.lib().afd_debug_conv_path(0)
         afdm.lib().afd_debug_conv_path(34)
         afdm.lib().afd_debug_conv_path(8)
+        afdm.lib().afd_debug_conv_path(80)
         afdm.lib().afd_debug_conv_path(64)
         afdm.lib().afd_debug_conv_path(96)
 
@@ -323,9 +327,9 @@ def test_conv_full_size_matches_double_precision_sample(A):
                          ids=lambda t: f"{t[0]}to{t[1]}_{t[2]}x{t[2]}")
 def test_conv_full_batch_winograd_vs_direct_and_fp64(A, shape):
     """BASELINE batch (256), the layer shapes of the Config-D decoder / bottleneck: the kernels the dispatch rule picks
-    (Winograd main kernel, small-map split-K kernel, Winograd wgrad) against the direct implicit-GEMM kernels on the
-    whole batch (two independent fp32 algorithms agreeing to ~1e-6), plus an fp64 spot check of forward, dgrad and
-    wgrad contributions on two images."""
+    (direct bf16x3 kernel, small-map split-K Winograd kernel, Winograd wgrad) and the fp32 Winograd main kernel (bf16x3
+    switched off) against the direct implicit-GEMM kernels on the whole batch (independent algorithms agreeing to
+    ~1e-6), plus an fp64 spot check of forward, dgrad and wgrad contributions on two images."""
     afdm, ops, dev = A
     ci, co, S = shape
     g = _g(ci + co + S)
@@ -335,7 +339,7 @@ def test_conv_full_batch_winograd_vs_direct_and_fp64(A, shape):
     L = afdm.lib()
     out = {}
     try:
-        for name, modes in (("rule", (64, 96)), ("direct", (65, 97))):
+        for name, modes in (("rule", (64, 96, 80)), ("wino", (64, 96, 81)), ("direct", (65, 97, 81))):
             for m in modes:
                 L.afd_debug_conv_path(m)
             xd, wd = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
@@ -345,9 +349,12 @@ def test_conv_full_batch_winograd_vs_direct_and_fp64(A, shape):
     finally:
         L.afd_debug_conv_path(64)
         L.afd_debug_conv_path(96)
-    assert L.afd_conv3x3_wino_workspace_bytes(256, ci, co, S, S, 0) > 0          # the rule really took a Winograd kernel
-    for a, b, what in zip(out["rule"], out["direct"], ("y", "dx", "dw")):
-        assert rel_l2(a.cpu(), b.cpu()) < 3e-6, what
+        L.afd_debug_conv_path(80)
+    assert L.afd_conv3x3_wino_workspace_bytes(256, ci, co, S, S, 0) > 0          # the rule really took a transformed-weight kernel
+    assert (L.afd_conv3x3_weight_kinds(256, ci, co, S, S) == 3) == (S >= 8)      # ... the bf16x3 one on the 8x8 and larger maps
+    for leg in ("rule", "wino"):
+        for a, b, what in zip(out[leg], out["direct"], ("y", "dx", "dw")):
+            assert rel_l2(a.cpu(), b.cpu()) < 3e-6, (leg, what)
     for i in (3, 254):
         xi = x[i:i + 1].cpu().double().requires_grad_(True)
         yi = F.conv2d(xi, w.cpu().double(), padding=1)
@@ -361,6 +368,35 @@ def test_conv_full_batch_winograd_vs_direct_and_fp64(A, shape):
     wd = w.clone().requires_grad_(True)
     (dwd,) = torch.autograd.grad(ops.conv(x[sl].contiguous(), wd), wd, dy[sl].contiguous())
     assert rel_l2(dwd.cpu(), dws) < 1e-5
+
+
+def test_conv_weight_image_follows_the_batch_size(A):
+    """One weight tensor, one stream, batch sizes on both sides of the bf16x3 rule (the cached weight image of a layer is
+    the bf16x3 one above the rule's size and the Winograd one below; Winograd forced so that the small batch reads a
+    cached image at all): each call must find an image of ITS form."""
+    afdm, ops, dev = A
+    L = afdm.lib()
+    g = _g(77)
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(dev)
+    L.afd_debug_conv_path(67)
+    try:
+        assert [L.afd_conv3x3_weight_kinds(B, 64, 64, 32, 32) for B in (48, 4)] == [3, 0]
+        assert L.afd_conv3x3_wino_workspace_bytes(4, 64, 64, 32, 32, 0) > 0
+        ops.bump_param_epoch()
+        with torch.no_grad():
+            for B in (48, 4, 48, 4):
+                x = torch.randn(B, 64, 32, 32, generator=g)
+                y = ops.conv_infer(x.to(dev), w)
+                check("F5 conv fwd vs fp64", y.cpu(), F.conv2d(x.double(), w.cpu().double(), padding=1), TOL, ("image per batch size", B))
+        for B in (48, 4, 48):
+            x = torch.randn(B, 64, 32, 32, generator=g); dy = torch.randn(B, 64, 32, 32, generator=g)
+            xd = x.to(dev).requires_grad_(True)
+            (gx,) = torch.autograd.grad(ops.conv(xd, w), xd, dy.to(dev))
+            xo = x.double().requires_grad_(True)
+            (go,) = torch.autograd.grad(F.conv2d(xo, w.cpu().double(), padding=1), xo, dy.double())
+            check("F5 conv bwd vs fp64", gx.cpu(), go, TOL, ("image per batch size", B, "dx"))
+    finally:
+        L.afd_debug_conv_path(64)
 
 
 def test_pointwise_full_batch_matches_double_precision(A):
