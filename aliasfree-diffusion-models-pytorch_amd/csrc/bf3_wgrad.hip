@@ -1,0 +1,283 @@
+// bf3_wgrad.hip -- F5: weight gradient of the 3x3 (pad 1) convolution on the bf16 matrix cores at fp32 accuracy (round 2).
+//
+//   dW[n][k][ty][tx] = sum over (image, pixel p) of dY[n][p] * X[k][p + (ty-1) W + (tx-1)]
+//
+// is a GEMM whose REDUCTION runs over pixels.  Both operands split exactly into three bf16 pieces (bf3_weights.h) and the
+// six leading cross terms go to v_mfma_f32_16x16x32_bf16 -- 6/16 of an fp32-MFMA per multiply instead of Winograd's
+// 16/36, on the matrix pipe instead of the vector pipe (wgrad_wino of wino.hip is bound by the fp32 MFMA issue rate).
+//
+// The MFMA wants, per lane, 8 CONSECUTIVE reduction elements of one row / column = 8 consecutive pixels of one channel.
+// A tap shifts X by (ty-1) rows and (tx-1) columns.  The row shift is a whole number of 8-pixel groups (W = 8, 16, 32),
+// the column shift is not -- so the column shift moves to the dY side (re-index q = p + tx - 1):
+//
+//   dW[n][k][ty][tx] = sum_q dY[n][q - (tx-1)] * X[k][q + (ty-1) W],       dY taken as 0 outside its row
+//
+//   B operand (X):  staged once per 128-pixel tile, split, kept in LDS as 16-byte records [piece][16-channel block][group
+//                   of 8 pixels, halo rows zero][channel]; the fragment of lane (channel l & 15, group l >> 4) for row
+//                   shift ty is ONE ds_read_b128 (consecutive lanes = consecutive records: conflict-free).
+//   A operand (dY): each wave reads ITS 16 output channels straight from global memory (32 contiguous bytes per lane +
+//                   the two neighbours), splits the 10 values once and packs the three column-shifted fragments from them
+//                   in registers.
+//   A workgroup (8 waves) owns BN x BK = 64 / 32 output x 64 / 32 input channels and a range of pixel tiles; a wave role
+//   (ns, kh) accumulates 16 n x 32 k x 9 taps (72 accumulator registers).  With fewer than 8 roles (32-channel layers)
+//   the 8 / roles wave groups take the 32-pixel steps of a tile in turn and are summed through LDS at the end.  Partial slabs
+//   [split][tap][cout][cin] + the deterministic wgrad_reduce of conv.hip, as for the other wgrad forms.
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include "common.h"
+#include "bf3_weights.h"
+
+namespace afd {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+template <int S, int BN_, int BK_> struct BwGeo {
+  static constexpr int TP = 128, G8 = S / 8;                          // pixels per tile, 8-pixel groups per row
+  static constexpr int IPT = S * S >= TP ? 1 : TP / (S * S);          // images per tile
+  static constexpr int R = S * S >= TP ? TP / S : S;                  // rows per image in the tile
+  static constexpr int TPI = S * S >= TP ? S * S / TP : 1;            // tiles per image
+  static constexpr int IG = (R + 2) * G8, NG = IPT * IG;              // groups per image incl. the two halo rows / per tile
+  static constexpr int BK = BK_, BN = BN_;
+  static constexpr int NR = (BN / 16) * (BK / 32), NSG = 8 / NR;      // wave roles, wave groups sharing a tile's steps
+  static constexpr int TASKS = (BK / 16) * NG * 16, NE = (TASKS + 511) / 512;
+  static constexpr int PIECE = (BK / 16) * NG * 16;                   // records per piece
+};
+
+__device__ __forceinline__ uint32_t bf_pack(__bf16 lo, __bf16 hi) {
+  return (uint32_t)__builtin_bit_cast(uint16_t, lo) | ((uint32_t)__builtin_bit_cast(uint16_t, hi) << 16);
+}
+
+template <int S, int BN, int BK>
+__global__ __launch_bounds__(512, 1) void wgrad_bf3(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                    int B, int K, int N, int tiles_per_split, int ntiles) {
+  using G = BwGeo<S, BN, BK>;
+  constexpr int HW = S * S, G8 = G::G8, NG = G::NG, NE = G::NE, PIECE = G::PIECE, NSG = G::NSG;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  bf8* Xs = reinterpret_cast<bf8*>(smem_raw);                         // [piece 3][ksub BK / 16][NG][16] records
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kgl = lane >> 4;
+  const int role = wv % G::NR, sg = wv / G::NR;                       // wave group sg takes steps sg, sg + NSG, ..
+  const int ns = role % (BN / 16), kh = role / (BN / 16);             // this wave: output channels n0 + 16 ns .., input channels k0 + 32 kh ..
+  const int nkb = blockIdx.y, nbk = N / G::BN;
+  const int n0 = (nkb % nbk) * G::BN, k0 = (nkb / nbk) * G::BK;
+  const int split = blockIdx.x;
+  const int tbeg = split * tiles_per_split, tend = min(ntiles, tbeg + tiles_per_split);
+
+  // ---- X staging plan: task = one record (16-channel block, group, channel)
+  int s_off[NE], s_rr[NE];                                            // element offset less the tile base; halo-inclusive row (-1: no task)
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int t = tid + 512 * e;
+    s_rr[e] = -1; s_off[e] = 0;
+    if (t < G::TASKS) {
+      const int c16 = t & 15, g = (t >> 4) % NG, ksub = t / (16 * NG);
+      const int i = g / G::IG, rem = g - i * G::IG, rr = rem / G8, c8 = rem - rr * G8;
+      s_rr[e] = rr | (i << 8);
+      s_off[e] = (i * K + ksub * 16 + c16) * HW + (rr - 1) * S + c8 * 8;
+    }
+  }
+  float xr[NE][8];
+  auto x_fetch = [&](int tile) {
+    const int img0 = G::IPT > 1 ? tile * G::IPT : tile / G::TPI;
+    const int row0 = G::IPT > 1 ? 0 : (tile % G::TPI) * G::R;
+    const float* xb = x + ((long)img0 * K + k0) * HW + row0 * S;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int rr = s_rr[e] & 255, i = s_rr[e] >> 8, yy = row0 + rr - 1;
+      const bool ok = s_rr[e] >= 0 && yy >= 0 && yy < S && img0 + i < B;
+      const float4* p = reinterpret_cast<const float4*>(xb + (ok ? s_off[e] : 0));
+      const float4 a = ok ? p[0] : make_float4(0.f, 0.f, 0.f, 0.f), b = ok ? p[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+      xr[e][0] = a.x; xr[e][1] = a.y; xr[e][2] = a.z; xr[e][3] = a.w; xr[e][4] = b.x; xr[e][5] = b.y; xr[e][6] = b.z; xr[e][7] = b.w;
+    }
+  };
+  auto x_commit = [&]() {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      if (s_rr[e] < 0) continue;
+      bf8 p0, p1, p2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { __bf16 a, b, c; bf3_split(xr[e][j], a, b, c); p0[j] = a; p1[j] = b; p2[j] = c; }
+      const int t = tid + 512 * e;
+      Xs[t] = p0; Xs[PIECE + t] = p1; Xs[2 * PIECE + t] = p2;
+    }
+  };
+
+  // ---- dY: lane (row n = l & 15, pixel group l >> 4 of the 32-pixel step) loads dy[p0 - 1 .. p0 + 8]
+  float dv[10];
+  const float* dyw = dy + (long)(n0 + 16 * ns + l15) * HW;
+  auto d_fetch = [&](int tile, int step) {
+    const int img0 = G::IPT > 1 ? tile * G::IPT : tile / G::TPI;
+    const int row0 = G::IPT > 1 ? 0 : (tile % G::TPI) * G::R;
+    const int pg = 4 * step + kgl;                                     // 8-pixel group of the tile
+    const int i = pg / (G::R * G8), rem = pg - i * (G::R * G8), r = rem / G8, c8 = rem - r * G8;
+    const bool ok = img0 + i < B;
+    const float* p = dyw + (long)(img0 + i) * N * HW + (row0 + r) * S + c8 * 8;
+    const float4 a = ok ? reinterpret_cast<const float4*>(p)[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b = ok ? reinterpret_cast<const float4*>(p)[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    dv[1] = a.x; dv[2] = a.y; dv[3] = a.z; dv[4] = a.w; dv[5] = b.x; dv[6] = b.y; dv[7] = b.z; dv[8] = b.w;
+    dv[0] = (G8 > 1 && ok && c8 > 0) ? p[-1] : 0.f;                    // the row's edge: dY outside its row counts as 0
+    dv[9] = (G8 > 1 && ok && c8 < G8 - 1) ? p[8] : 0.f;
+  };
+
+  f32x4 acc[2][9];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[ks][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // B fragment of (16-channel block ks of this wave's half, row shift ty) at step `step`: record (piece, ksub, group, channel)
+  const int brec0 = ((2 * kh) * NG) * 16 + l15;
+  auto b_group = [&](int step) {                                       // halo-inclusive group index of this lane's 8 pixels, row shift 0
+    const int pg = 4 * step + kgl;
+    const int i = pg / (G::R * G8), rem = pg - i * (G::R * G8), r = rem / G8, c8 = rem - r * G8;
+    return i * G::IG + (r + 1) * G8 + c8;
+  };
+
+  if (tbeg < tend) { x_fetch(tbeg); d_fetch(tbeg, sg); }
+  for (int tile = tbeg; tile < tend; ++tile) {
+    __syncthreads();                                                   // the previous tile's fragment reads are done
+    x_commit();
+    __syncthreads();
+    if (tile + 1 < tend) x_fetch(tile + 1);                            // in flight during the multiplies
+#pragma unroll 1
+    for (int step = sg; step < 4; step += NSG) {
+      // ---- A fragments: split the 10 dY values once, pack the three column shifts (tx = 0, 1, 2 <-> dY[q+1], dY[q], dY[q-1])
+      __bf16 pc[3][10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) bf3_split(dv[j], pc[0][j], pc[1][j], pc[2][j]);
+      bf8 af[3][3];                                                    // [tx][piece]
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        u32x4 e0, e1, e2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          e0[q] = bf_pack(pc[p][2 * q + 2], pc[p][2 * q + 3]);         // tx = 0: v[j + 2]
+          e1[q] = bf_pack(pc[p][2 * q + 1], pc[p][2 * q + 2]);         // tx = 1: v[j + 1]
+          e2[q] = bf_pack(pc[p][2 * q], pc[p][2 * q + 1]);             // tx = 2: v[j]
+        }
+        af[0][p] = __builtin_bit_cast(bf8, e0); af[1][p] = __builtin_bit_cast(bf8, e1); af[2][p] = __builtin_bit_cast(bf8, e2);
+      }
+      // the next step's dY (or the next tile's first) in flight during the multiplies
+      if (step + NSG < 4) d_fetch(tile, step + NSG); else if (tile + 1 < tend) d_fetch(tile + 1, sg);
+
+      const int gb = brec0 + b_group(step) * 16;
+      bf8 bc[3], bn[3];
+      { const int o = gb - G8 * 16; bc[0] = Xs[o]; bc[1] = Xs[PIECE + o]; bc[2] = Xs[2 * PIECE + o]; }
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {                                    // unit = (channel block ks, row shift ty)
+        const int ks = u / 3, ty = u % 3;
+        if (u + 1 < 6) {
+          const int ksn = (u + 1) / 3, tyn = (u + 1) % 3;
+          const int o = gb + ksn * NG * 16 + (tyn - 1) * G8 * 16;
+          bn[0] = Xs[o]; bn[1] = Xs[PIECE + o]; bn[2] = Xs[2 * PIECE + o];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          f32x4 c = acc[ks][ty * 3 + tx];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][0], bc[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][1], bc[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][0], bc[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][2], bc[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][1], bc[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][0], bc[2], c, 0, 0, 0);
+          acc[ks][ty * 3 + tx] = c;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2];
+      }
+    }
+  }
+
+  // ---- wave groups 1 .. NSG-1 hand their sums to group 0 through LDS, in a fixed order
+  if (NSG > 1) {
+    float* red = reinterpret_cast<float*>(smem_raw);                  // [role][72][64]
+#pragma unroll 1
+    for (int g = 1; g < NSG; ++g) {
+      __syncthreads();                                                 // (first round: the last tile's fragment reads are done)
+      if (sg == g) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) red[(role * 72 + (ks * 9 + t) * 4 + rg) * 64 + lane] = acc[ks][t][rg];
+      }
+      __syncthreads();
+      if (sg == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) acc[ks][t][rg] += red[(role * 72 + (ks * 9 + t) * 4 + rg) * 64 + lane];
+      }
+    }
+    if (sg != 0) return;
+  }
+  // ---- epilogue: accumulator (row n = 4 (l >> 4) + reg, column k = l & 15) -> slab [split][tap][cout][cin]
+  float* ps = part + (long)split * 9 * N * K;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+        ps[((long)t * N + n0 + 16 * ns + 4 * kgl + rg) * K + k0 + 32 * kh + 16 * ks + l15] = acc[ks][t][rg];
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------
+static int g_wgbf3_mode = 0;       // afd_debug_conv_path 84 / 85 / 86: by the rule / off / wherever the shape is covered
+void wgrad_bf3_set_mode(int m) { g_wgbf3_mode = m; }
+
+// plan: the number of slabs (0 = not covered / not chosen) and the tiles per split
+int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles) {
+  if (g_wgbf3_mode == 1) return 0;
+  if (H != W || (W != 8 && W != 16 && W != 32)) return 0;
+  if (Cin % 32 || Cout % 32) return 0;
+  if ((long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return 0;
+  const long nt = W == 8 ? (B + 1) / 2 : (long)B * (H * W / 128);
+  const int BN = Cout % 64 == 0 ? 64 : 32, BK = Cin % 64 == 0 ? 64 : 32;
+  const long blocks = (long)(Cout / BN) * (Cin / BK);
+  static const long target = [] { const char* e = getenv("AFD_WGB_TARGET"); return e ? atol(e) : 256L; }();   // tuning hook
+  long s = target / blocks;
+  if (s < 1) s = 1;
+  if (s > nt) s = nt;
+  const long c = (nt + s - 1) / s;
+  if (g_wgbf3_mode != 2 && nt * blocks < 128) return 0;               // too little work to fill half the chip: the other forms
+  *tps = (int)c; *ntiles = (int)nt;
+  return (int)((nt + c - 1) / c);
+}
+
+template <int S, int BN, int BK>
+static void wgrad_bf3_launch_t(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int tps, int nt, int splits,
+                               hipStream_t s) {
+  using G = BwGeo<S, BN, BK>;
+  const size_t lds = std::max((size_t)3 * G::PIECE * 16, G::NSG > 1 ? sizeof(float) * G::NR * 72 * 64 : (size_t)0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf3<S, BN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_bf3<S, BN, BK>), dim3((unsigned)splits, (unsigned)((Cout / BN) * (Cin / BK))), dim3(512), lds, s, x, dy,
+                     part, B, Cin, Cout, tps, nt);
+}
+
+// writes `slabs` partial [9][Cout][Cin] slabs into part; the caller reduces them (wgrad_reduce)
+int wgrad_bf3(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s) {
+  int tps, nt;
+  const int splits = wgrad_bf3_plan(B, Cin, Cout, H, W, &tps, &nt);
+  if (!splits) return 0;
+  const bool n64 = Cout % 64 == 0, k64 = Cin % 64 == 0;
+#define AFD_WGB(S_)                                                                                       \
+  if (n64 && k64) wgrad_bf3_launch_t<S_, 64, 64>(x, dy, part, B, Cin, Cout, tps, nt, splits, s);          \
+  else if (n64) wgrad_bf3_launch_t<S_, 64, 32>(x, dy, part, B, Cin, Cout, tps, nt, splits, s);            \
+  else if (k64) wgrad_bf3_launch_t<S_, 32, 64>(x, dy, part, B, Cin, Cout, tps, nt, splits, s);            \
+  else wgrad_bf3_launch_t<S_, 32, 32>(x, dy, part, B, Cin, Cout, tps, nt, splits, s)
+  if (W == 32) { AFD_WGB(32); } else if (W == 16) { AFD_WGB(16); } else { AFD_WGB(8); }
+#undef AFD_WGB
+  return splits;
+}
+
+}  // namespace afd

@@ -805,6 +805,10 @@ void bf3_set_mode(int m);
 void wino_weights_batched_launch(const afd_wino_desc* descs, const int* wg_desc, int n_wg, hipStream_t s);
 void wino_set_grid(int g);
 int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, int* cps, int* nchunks);
+// bf3_wgrad.hip: the 3x3 weight gradient on the bf16 matrix cores (three-piece splits)
+int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles);
+int wgrad_bf3(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
+void wgrad_bf3_set_mode(int m);
 int wgrad_wino(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
 void wgrad_wino_set_mode(int m);
 
@@ -914,6 +918,7 @@ using namespace afd;
 extern "C" {
 
 int afd_debug_conv_path(int mode) {
+  if (mode >= 84 && mode <= 86) { wgrad_bf3_set_mode(mode - 84); return AFD_OK; }   // bf16x3 3x3 wgrad: 84 = by rule (default), 85 = off, 86 = wherever covered
   if (mode >= 80 && mode <= 82) { bf3_set_mode(mode - 80); return AFD_OK; }   // direct bf16x3 3x3 kernel: 80 = by rule (default), 81 = off, 82 = wherever covered
   if (mode >= 8 && mode <= 10) { pw_set_mode(mode - 8); return AFD_OK; }     // 1x1 streaming kernel: 8 = by rule (default), 9 = off, 10 = forced
   if (mode >= 100000 && mode < 200000) { wino_set_grid(mode - 100000); return AFD_OK; }   // Winograd persistent grid size (0 = default)
@@ -1012,6 +1017,8 @@ size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, in
     int bn, bk, cps, nch;
     const size_t ws = (size_t)wgrad_wino_plan(B, Cin, Cout, H, W, &bn, &bk, &cps, &nch);
     if (ws > slabs) slabs = ws;
+    const size_t wb = (size_t)wgrad_bf3_plan(B, Cin, Cout, H, W, &cps, &nch);
+    if (wb > slabs) slabs = wb;
   }
   const size_t need = slabs * ((size_t)Cout * Cin * ksize * ksize + Cout);
   const size_t direct = (size_t)B * Cout;
@@ -1025,9 +1032,10 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
   hipStream_t s = as_stream(st);
   const int T = ksize * ksize;
   const TileGeom g = make_geom(H, W, 64, ksize == 3 ? 1 : 0);
-  if (ksize == 3 && !dbias && workspace) {                               // Winograd F(3x3, 2x2) form: 16 multiplies per tile instead of 36
+  if (ksize == 3 && !dbias && workspace) {                               // bf16x3 form on the matrix pipe, else Winograd F(3x3, 2x2): 16 multiplies per tile instead of 36
     float* part = static_cast<float*>(workspace);
-    const int slabs = wgrad_wino(x, dy, part, B, Cin, Cout, H, W, s);
+    int slabs = wgrad_bf3(x, dy, part, B, Cin, Cout, H, W, s);
+    if (!slabs) slabs = wgrad_wino(x, dy, part, B, Cin, Cout, H, W, s);
     if (slabs) {
       const long n = (long)Cout * Cin * 9;
       launch_wgrad_reduce(part, dw, n, slabs, nullptr, nullptr, 0, accumulate, 9, s);

@@ -258,11 +258,11 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "bf3", "nobf3", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "winosk", "nowino", "wgwino", "nowgwino"])
+@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "bf3", "nobf3", "wgbf3", "nowgbf3", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "winosk", "nowino", "wgwino", "nowgwino"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[5]}" for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(A, case, path):
     afdm, ops, dev = A
-    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10, "bf3": 82, "nobf3": 81,
+    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10, "bf3": 82, "nobf3": 81, "wgbf3": 86, "nowgbf3": 85,
                                         "wino64x64": 66, "wino32x64": 67, "wino64x32": 68, "wino32x32": 69, "winosk": 70, "nowino": 65, "wgwino": 98, "nowgwino": 97}[path])
     try:
         _conv_case(ops, dev, case)
@@ -271,6 +271,7 @@ def test_conv_fwd_dgrad_wgrad(A, case, path):
         afdm.lib().afd_debug_conv_path(34)
         afdm.lib().afd_debug_conv_path(8)
         afdm.lib().afd_debug_conv_path(80)
+        afdm.lib().afd_debug_conv_path(84)
         afdm.lib().afd_debug_conv_path(64)
         afdm.lib().afd_debug_conv_path(96)
 
@@ -339,7 +340,7 @@ def test_conv_full_batch_winograd_vs_direct_and_fp64(A, shape):
     L = afdm.lib()
     out = {}
     try:
-        for name, modes in (("rule", (64, 96, 80)), ("wino", (64, 96, 81)), ("direct", (65, 97, 81))):
+        for name, modes in (("rule", (64, 96, 80, 84)), ("wino", (64, 96, 81, 85)), ("direct", (65, 97, 81, 85))):
             for m in modes:
                 L.afd_debug_conv_path(m)
             xd, wd = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
@@ -350,6 +351,7 @@ def test_conv_full_batch_winograd_vs_direct_and_fp64(A, shape):
         L.afd_debug_conv_path(64)
         L.afd_debug_conv_path(96)
         L.afd_debug_conv_path(80)
+        L.afd_debug_conv_path(84)
     assert L.afd_conv3x3_wino_workspace_bytes(256, ci, co, S, S, 0) > 0          # the rule really took a transformed-weight kernel
     assert (L.afd_conv3x3_weight_kinds(256, ci, co, S, S) == 3) == (S >= 8)      # ... the bf16x3 one on the 8x8 and larger maps
     for leg in ("rule", "wino"):
