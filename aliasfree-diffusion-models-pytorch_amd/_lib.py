@@ -42,7 +42,7 @@ def parse_header(path=HEADER):
     return out
 
 
-_VALUE_RETURNING = {"afd_device_count", "afd_tok_supported", "afd_conv3x3_weight_kinds"}      # int results, not status codes
+_VALUE_RETURNING = {"afd_device_count", "afd_tok_supported", "afd_conv3x3_weight_kinds", "afd_conv_wgrad_form"}      # int results, not status codes
 
 
 class AfdError(RuntimeError):

@@ -172,15 +172,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf3(const float* __restrict__ x, 
         if (BF3_ABL & 1) {
           asm volatile("" :: "v"(a[0][0]), "v"(a[0][1]), "v"(a[0][2]), "v"(a[1][0]), "v"(bc[0]), "v"(bc[1]), "v"(bc[2]));
         } else {
+          // term-major: consecutive MFMAs go to different accumulators (a dependent pair would wait out the pipeline depth)
+          constexpr int TA[6] = {0, 1, 0, 2, 1, 0}, TB[6] = {0, 0, 1, 0, 1, 2};
 #pragma unroll
-          for (int ns = 0; ns < 2; ++ns) {
-            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][0], bc[0], acc[ns][ps], 0, 0, 0);
-            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][1], bc[0], acc[ns][ps], 0, 0, 0);
-            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][0], bc[1], acc[ns][ps], 0, 0, 0);
-            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][2], bc[0], acc[ns][ps], 0, 0, 0);
-            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][1], bc[1], acc[ns][ps], 0, 0, 0);
-            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][0], bc[2], acc[ns][ps], 0, 0, 0);
-          }
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int ns = 0; ns < 2; ++ns)
+              acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][TA[t]], bc[TB[t]], acc[ns][ps], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!(BF3_ABL & 8)) { bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2]; }

@@ -173,16 +173,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3(const float* __restrict__ x,
           bn[0] = Xs[o]; bn[1] = Xs[PIECE + o]; bn[2] = Xs[2 * PIECE + o];
         }
         __builtin_amdgcn_sched_barrier(0);
+        {  // term-major over the three column shifts: consecutive MFMAs go to different accumulators
+          constexpr int TA[6] = {0, 1, 0, 2, 1, 0}, TB[6] = {0, 0, 1, 0, 1, 2};
 #pragma unroll
-        for (int tx = 0; tx < 3; ++tx) {
-          f32x4 c = acc[ks][ty * 3 + tx];
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][0], bc[0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][1], bc[0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][0], bc[1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][2], bc[0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][1], bc[1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][0], bc[2], c, 0, 0, 0);
-          acc[ks][ty * 3 + tx] = c;
+          for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+              acc[ks][ty * 3 + tx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][TA[t]], bc[TB[t]], acc[ks][ty * 3 + tx], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2];
@@ -225,6 +222,122 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3(const float* __restrict__ x,
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg)
         ps[((long)t * N + n0 + 16 * ns + 4 * kgl + rg) * K + k0 + 32 * kh + 16 * ks + l15] = acc[ks][t][rg];
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions / token Linear layers:  dW[n][k] = sum_p dY[n][p] X[k][p],  db[n] = sum_p dY[n][p]
+// No shifts, so BOTH operands come straight from global memory: lane (channel l & 15, pixel group l >> 4) loads 32
+// contiguous bytes, splits them and holds the fragments of a 32-pixel step.  A wave owns 16 NT output x 32 input channels;
+// the 8 waves of a workgroup are (output tile, input tile) roles x pixel slices, summed through LDS at the end; the pixel
+// range is split over workgroups (slabs [split][cout][cin] + bias slabs, reduced by wgrad_reduce).  Each operand element
+// is read once per role that needs it (L2) and once from HBM: the kernel is HBM-bound.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(512, 1) void pw_wgrad_bf3(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                       float* __restrict__ bias_part, int B, int K, int N, int L, int steps_per_split,
+                                                       int nsteps, int NR) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kgl = lane >> 4;
+  const int WP = 8 / NR;                                               // pixel slices per workgroup
+  const int role = blockIdx.y * NR + wv % NR, wp = wv / NR;
+  const int ntn = N / (16 * NT);
+  const int n0 = (role % ntn) * 16 * NT, k0 = (role / ntn) * 32;
+  const int split = blockIdx.x;
+  const int sbeg = split * steps_per_split, send = min(nsteps, sbeg + steps_per_split);
+
+  f32x4 acc[NT][2];
+  float bsum[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) { bsum[i] = 0.f; acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+
+  float4 ra[NT][2], rb[2][2];
+  auto fetch = [&](int t) {
+    const long P0 = 32L * t;
+    const long b = P0 / L, p = P0 - b * L + 8 * kgl;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const float4* q = reinterpret_cast<const float4*>(dy + (b * N + n0 + 16 * i + l15) * L + p);
+      ra[i][0] = q[0]; ra[i][1] = q[1];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float4* q = reinterpret_cast<const float4*>(x + (b * K + k0 + 16 * j + l15) * L + p);
+      rb[j][0] = q[0]; rb[j][1] = q[1];
+    }
+  };
+  auto split8 = [&](const float4& u, const float4& v, bf8 (&f)[3]) {
+    const float e[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { __bf16 a, b, c; bf3_split(e[j], a, b, c); f[0][j] = a; f[1][j] = b; f[2][j] = c; }
+  };
+  if (sbeg + wp < send) fetch(sbeg + wp);
+#pragma unroll 1
+  for (int t = sbeg + wp; t < send; t += WP) {
+    bf8 fa[NT][3], fb[2][3];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      split8(ra[i][0], ra[i][1], fa[i]);
+      bsum[i] += ((ra[i][0].x + ra[i][0].y) + (ra[i][0].z + ra[i][0].w)) + ((ra[i][1].x + ra[i][1].y) + (ra[i][1].z + ra[i][1].w));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) split8(rb[j][0], rb[j][1], fb[j]);
+    if (t + WP < send) fetch(t + WP);                                  // in flight during the multiplies
+    constexpr int TA[6] = {0, 1, 0, 2, 1, 0}, TB[6] = {0, 0, 1, 0, 1, 2};
+#pragma unroll
+    for (int m = 0; m < 6; ++m)
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][TA[m]], fb[j][TB[m]], acc[i][j], 0, 0, 0);
+  }
+  // bias: the four pixel groups of a row sit in lanes l15, l15 + 16, + 32, + 48
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    bsum[i] += __shfl_xor(bsum[i], 16, kWave);
+    bsum[i] += __shfl_xor(bsum[i], 32, kWave);
+  }
+  // pixel slices 1 .. WP-1 hand their sums to slice 0 through LDS, in a fixed order
+  float* red = reinterpret_cast<float*>(smem_raw);                    // [role in workgroup][NT * 8 + NT][64]
+  const int rl = wv % NR;
+#pragma unroll 1
+  for (int g = 1; g < WP; ++g) {
+    __syncthreads();
+    if (wp == g) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) red[(rl * (NT * 9) + (i * 2 + j) * 4 + rg) * 64 + lane] = acc[i][j][rg];
+        red[(rl * (NT * 9) + NT * 8 + i) * 64 + lane] = bsum[i];
+      }
+    }
+    __syncthreads();
+    if (wp == 0) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) acc[i][j][rg] += red[(rl * (NT * 9) + (i * 2 + j) * 4 + rg) * 64 + lane];
+        bsum[i] += red[(rl * (NT * 9) + NT * 8 + i) * 64 + lane];
+      }
+    }
+  }
+  if (wp != 0) return;
+  float* ps = part + (long)split * N * K;
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) ps[(long)(n0 + 16 * i + 4 * kgl + rg) * K + k0 + 16 * j + l15] = acc[i][j][rg];
+  if (bias_part && k0 == 0 && kgl == 0) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) bias_part[(long)split * N + n0 + 16 * i + l15] = bsum[i];
+  }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -277,6 +390,39 @@ int wgrad_bf3(const float* x, const float* dy, float* part, int B, int Cin, int 
   else wgrad_bf3_launch_t<S_, 32, 32>(x, dy, part, B, Cin, Cout, tps, nt, splits, s)
   if (W == 32) { AFD_WGB(32); } else if (W == 16) { AFD_WGB(16); } else { AFD_WGB(8); }
 #undef AFD_WGB
+  return splits;
+}
+
+
+// 1x1 plan: slabs (0 = not covered / not chosen); fills the steps per split, the roles per workgroup and NT
+int pw_wgrad_bf3_plan(int B, int Cin, int Cout, int L, int* sps, int* nsteps, int* nr, int* nt) {
+  if (g_wgbf3_mode == 1) return 0;
+  if (Cin % 32 || Cout % 32 || L % 32) return 0;
+  if ((long)B * L * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return 0;
+  const int NT = Cout % 48 == 0 ? 3 : 2;
+  const int roles = (Cout / (16 * NT)) * (Cin / 32);
+  int NR = 8;
+  while (roles % NR) NR >>= 1;                                         // roles per workgroup: a power of two dividing the role count
+  const long st = (long)B * L / 32;
+  const long gy = roles / NR;
+  static const long target = [] { const char* e = getenv("AFD_PWB_TARGET"); return e ? atol(e) : 256L; }();   // tuning hook
+  long s = target / gy;
+  if (s < 1) s = 1;
+  if (s > st) s = st;
+  const long c = (st + s - 1) / s;
+  *sps = (int)c; *nsteps = (int)st; *nr = NR; *nt = NT;
+  return (int)((st + c - 1) / c);
+}
+
+int pw_wgrad_bf3(const float* x, const float* dy, float* part, float* bias_part, int B, int Cin, int Cout, int L, hipStream_t s) {
+  int sps, st, NR, NT;
+  const int splits = pw_wgrad_bf3_plan(B, Cin, Cout, L, &sps, &st, &NR, &NT);
+  if (!splits) return 0;
+  const int roles = (Cout / (16 * NT)) * (Cin / 32);
+  const size_t lds = 8 / NR > 1 ? sizeof(float) * NR * NT * 9 * 64 : 0;
+  const dim3 grid((unsigned)splits, (unsigned)(roles / NR));
+  if (NT == 3) hipLaunchKernelGGL(pw_wgrad_bf3<3>, grid, dim3(512), lds, s, x, dy, part, bias_part, B, Cin, Cout, L, sps, st, NR);
+  else hipLaunchKernelGGL(pw_wgrad_bf3<2>, grid, dim3(512), lds, s, x, dy, part, bias_part, B, Cin, Cout, L, sps, st, NR);
   return splits;
 }
 

@@ -11,6 +11,7 @@
 // from OIHW (no transform pass) into rows of odd stride, which makes every fragment read
 // conflict-free.  fp32 in / fp32 accumulate: bitwise an fma chain, no reduced precision anywhere.
 #include <cstdlib>
+#include <algorithm>
 #include "common.h"
 
 namespace afd {
@@ -809,6 +810,8 @@ int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, in
 int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles);
 int wgrad_bf3(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
 void wgrad_bf3_set_mode(int m);
+int pw_wgrad_bf3_plan(int B, int Cin, int Cout, int L, int* sps, int* nsteps, int* nr, int* nt);
+int pw_wgrad_bf3(const float* x, const float* dy, float* part, float* bias_part, int B, int Cin, int Cout, int L, hipStream_t s);
 int wgrad_wino(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
 void wgrad_wino_set_mode(int m);
 
@@ -1010,10 +1013,15 @@ int afd_conv3x3_wino_dgrad(const float* dy, const float* w, float* dx, const flo
 
 size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ksize) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
-  if (!tile_ok(H, W, 64)) return sizeof(float) * (size_t)B * Cout;
+  size_t pw = 0;                                                          // the 1x1 bf16x3 form: [slabs][Cout*Cin] + [slabs][Cout]
+  if (ksize == 1) {
+    int a, b, c, d;
+    pw = sizeof(float) * (size_t)pw_wgrad_bf3_plan(B, Cin, Cout, H * W, &a, &b, &c, &d) * ((size_t)Cout * Cin + Cout);
+  }
+  if (!tile_ok(H, W, 64)) return std::max(pw, sizeof(float) * (size_t)B * Cout);
   // [slabs][Cout*Cin*T] weight slabs, then [slabs][Cout] bias slabs; the direct path wants (B, Cout) plane sums
   size_t slabs = wgrad_plan(B, Cin, Cout, H, W, ksize).slabs;
-  if (ksize == 3) {                                                      // the Winograd form may split finer
+  if (ksize == 3) {                                                      // the Winograd / bf16x3 forms may split finer
     int bn, bk, cps, nch;
     const size_t ws = (size_t)wgrad_wino_plan(B, Cin, Cout, H, W, &bn, &bk, &cps, &nch);
     if (ws > slabs) slabs = ws;
@@ -1022,7 +1030,16 @@ size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, in
   }
   const size_t need = slabs * ((size_t)Cout * Cin * ksize * ksize + Cout);
   const size_t direct = (size_t)B * Cout;
-  return sizeof(float) * (need > direct ? need : direct);
+  return std::max(pw, sizeof(float) * (need > direct ? need : direct));
+}
+
+int afd_conv_wgrad_form(int B, int Cin, int Cout, int H, int W, int ksize) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  int a, b, c, d;
+  if (ksize == 1) return pw_wgrad_bf3_plan(B, Cin, Cout, H * W, &a, &b, &c, &d) ? 2 : 0;
+  if (ksize != 3) return 0;
+  if (wgrad_bf3_plan(B, Cin, Cout, H, W, &a, &b)) return 2;
+  return wgrad_wino_plan(B, Cin, Cout, H, W, &a, &b, &c, &d) ? 1 : 0;
 }
 
 int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
@@ -1039,6 +1056,18 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
     if (slabs) {
       const long n = (long)Cout * Cin * 9;
       launch_wgrad_reduce(part, dw, n, slabs, nullptr, nullptr, 0, accumulate, 9, s);
+      return check_launch("afd_conv_wgrad");
+    }
+  }
+  if (ksize == 1 && workspace) {                                         // bf16x3 form straight from global memory (HBM-bound)
+    int a, b, c, d;
+    const int slabs = pw_wgrad_bf3_plan(B, Cin, Cout, H * W, &a, &b, &c, &d);
+    if (slabs) {
+      float* part = static_cast<float*>(workspace);
+      const long n = (long)Cout * Cin;
+      float* bp = dbias ? part + (size_t)slabs * n : nullptr;
+      pw_wgrad_bf3(x, dy, part, bp, B, Cin, Cout, H * W, s);
+      launch_wgrad_reduce(part, dw, n, slabs, bp, dbias, dbias ? Cout : 0, accumulate, 1, s);
       return check_launch("afd_conv_wgrad");
     }
   }

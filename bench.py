@@ -29,6 +29,7 @@ import torch.distributed as dist
 F_SET = {"kernel_size": 3, "kaiser_beta": 2, "omega_c_down": math.pi / 2, "omega_c_up": math.pi / 2}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+MFMA_BF16_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: bf16 MFMA dense peak (the bf16x3 kernels issue 6 bf16 products per fp32 product)
 
 # Config D layer table: (Cin, Cout, HW side) of every 3x3 conv, forward order
 CONV3 = ([(3, 32, 32), (32, 32, 32)] + [(32, 32, 16)] * 2 + [(32, 64, 16), (64, 64, 16)] + [(64, 64, 8)] * 2 +
@@ -96,13 +97,20 @@ def kernel_table(dev, B):
 
     # ---- 3x3 convolutions (F5) -----------------------------------------------------------------------------------
     seen = {}
+
+    def pipe_s(fl, form):
+        """Seconds the matrix pipe needs AT PEAK for the multiplies the kernel form issues for `fl` algorithmic flops:
+        bf16x3 = 6 bf16 products per fp32 product on the bf16 MFMA, Winograd = 16/36 of the products on the fp32 MFMA."""
+        return {"bf3": 6.0 * fl / (MFMA_BF16_PEAK_TF * 1e12), "wino": 16.0 / 36.0 * fl / (MFMA_F32_PEAK_TF * 1e12),
+                "direct": fl / (MFMA_F32_PEAK_TF * 1e12)}[form]
+
     for (ci, co, S) in CONV3:
-        tf, td, tw, wf, wd = cached(seen, (ci, co, S), lambda: conv_layer_times(L, s, dev, B, ci, co, S))
+        tf, td, tw, ff, fd, fw = cached(seen, (ci, co, S), lambda: conv_layer_times(L, s, dev, B, ci, co, S))
         fl = 2.0 * B * S * S * ci * co * 9              # algorithmic (direct-form) flops of one pass
-        add("conv3x3_fwd", tf, fl, bound="mfma", wino=wf)
+        add("conv3x3_fwd", tf, fl, bound="mfma", pipe_s=pipe_s(fl, ff), **{ff: 1})
         if ci > 3:
-            add("conv3x3_dgrad", td, fl, bound="mfma", wino=wd)
-        add("conv3x3_wgrad", tw, fl, bound="mfma", wino=1 if (ci > 3) else 0)
+            add("conv3x3_dgrad", td, fl, bound="mfma", pipe_s=pipe_s(fl, fd), **{fd: 1})
+        add("conv3x3_wgrad", tw, fl, bound="mfma", pipe_s=pipe_s(fl, fw), **{fw: 1})
     # ---- filtered GELU (F4) + the GroupNorm kernels around it (F6) ------------------------------------------------
     seen = {}
     tk = ops.Taps(afdm.circularLowpassKernel(math.pi / 2, 3, 2))
@@ -224,11 +232,12 @@ def kernel_table(dev, B):
         frac = (tf / MFMA_F32_PEAK_TF) if r["bound"] == "mfma" else (gb / HBM_PEAK_GBS if gb else None)
         row = {"kernel": name, "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 4), "bound": r["bound"],
                "tflops": round(tf, 3) if tf else None, "gbs": round(gb, 1) if gb else None, "frac": round(frac, 4) if frac else None}
-        if "wino" in r:
-            # Winograd F(2x2,3x3) / F(3x3,2x2) issues 16 of the direct form's 36 multiplies: the fraction of the matrix peak the
-            # EXECUTED multiplies reach (launch-weighted: the few direct-form launches count in full)
-            row["winograd_launches"] = r["wino"]
-            row["frac_executed"] = round(frac * (16.0 / 36.0 * r["wino"] + (r["launches"] - r["wino"])) / r["launches"], 4)
+        if "pipe_s" in r:
+            # how the launches split over the kernel forms, and the fraction of the measured time the matrix pipe would need
+            # at the peak of the instruction each form issues (bf16x3: 6 bf16 products per fp32 product against the bf16 peak;
+            # Winograd: 16/36 of the products against the fp32 peak)
+            row["launches_by_form"] = {k: r[k] for k in ("bf3", "wino", "direct") if r.get(k)}
+            row["frac_executed"] = round(r["pipe_s"] / sec, 4)
         if name in pmc and pmc[name].get("mfma_busy_frac") is not None:
             row["mfma_busy_pmc"] = pmc[name]["mfma_busy_frac"]
         out.append(row)
@@ -240,12 +249,14 @@ def kernel_table(dev, B):
 
 def conv_layer_times(L, s, dev, B, ci, co, S, reps=5):
     """(fwd, dgrad, wgrad) ms of one 3x3 layer through the same dispatch the autograd shells use (ops.py): the
-    Winograd entry points where the library covers the shape (non-zero workspace), else the direct kernels.
-    Also returns whether forward / dgrad took the Winograd path."""
+    transformed-weight entry points where the library covers the shape (non-zero workspace: the bf16x3 direct kernel or
+    the fp32 Winograd kernels, the library's choice), else the direct kernels.  Also returns the form each pass took
+    ("bf3" | "wino" | "direct")."""
     x = torch.randn(B, ci, S, S, device=dev); w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
     y = torch.randn(B, co, S, S, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
     ws = torch.empty(max(L.afd_conv_wgrad_workspace_bytes(B, ci, co, S, S, 3) // 4, 1), device=dev)
     nf, nd = L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, 0), L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, 1)
+    kinds = L.afd_conv3x3_weight_kinds(B, ci, co, S, S)
     u = torch.empty(max(nf, nd, 4) // 4, device=dev)
     if nf:
         tf = ev_time(lambda: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, s), reps)
@@ -258,7 +269,8 @@ def conv_layer_times(L, s, dev, B, ci, co, S, reps=5):
     else:
         td = ev_time(lambda: L.afd_conv_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), B, ci, co, S, S, 3, s), reps)
     tw = ev_time(lambda: L.afd_conv_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, B, ci, co, S, S, 3, 0, ws.data_ptr(), s), reps)
-    return tf, td, tw, 1 if nf else 0, 1 if (nd and ci > 3) else 0
+    form = lambda n, bit: "direct" if not n else ("bf3" if kinds & bit else "wino")
+    return tf, td, tw, form(nf, 1), form(nd, 2), ("direct", "wino", "bf3")[L.afd_conv_wgrad_form(B, ci, co, S, S, 3)]
 
 
 def pmc_traffic(family, launches):
@@ -498,8 +510,10 @@ def main():
             sec = r["ms"] * 1e-3
             if r["bound"] == "mfma":
                 ach = r["flops"] / sec / 1e12
-                basis = ("algorithmic direct-form flops (2*9*Cin*Cout per output pixel, SURVEY 8d) / HIP-event time; the Winograd kernels issue 16/36 of "
-                         "those multiplies on the fp32 MFMA (frac_executed), so frac is not bounded by 1"
+                basis = ("algorithmic direct-form flops (2*9*Cin*Cout per output pixel, SURVEY 8d) / HIP-event time, priced against the fp32 matrix "
+                         "peak (the results are fp32); the large layers run on the bf16 MFMA with exact three-piece splits (6 bf16 products per "
+                         "fp32 product), the small maps on fp32 Winograd kernels (16/36 of the products), so frac is not bounded by 1: "
+                         "frac_executed prices each launch's issued products against the peak of ITS instruction (bf16 2500 / fp32 157.3 TFLOP/s)"
                          + ("; weight-gradient launches are sized to run on a second stream beside the backward chain, so timed alone, as here, they "
                             "do not fill the chip" if name == "conv3x3_wgrad" else "")) if name.startswith("conv") else \
                         ("algorithmic attention flops (4*L*L*C forward, 2.5x that backward, SURVEY 8d) / HIP-event time; fp32 results; head dim 8: "
@@ -507,6 +521,7 @@ def main():
                          "priced against the fp32 matrix peak")
                 result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                       "frac": round(ach / MFMA_F32_PEAK_TF, 4), "frac_executed": trow.get("frac_executed"),
+                                      "launches_by_form": trow.get("launches_by_form"), "peak_bf16": MFMA_BF16_PEAK_TF,
                                       "mfma_busy_pmc": trow.get("mfma_busy_pmc"), "traffic": traffic,
                                       "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3),
                                       "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2), "basis": basis, "traffic_source": tsrc}

@@ -112,13 +112,19 @@ int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, in
  * 2 = always the 32x64 in-workgroup split-K tile (when the shape allows it);
  * 8 / 9 / 10 = 1x1 streaming kernel chosen by the measured rule (default) / never / whenever the shape is covered;
  * 32 / 33 / 34 = wgrad workgroups of 4 waves / 8 waves / chosen per layer (default);
- * 96 / 97 / 98 = Winograd form of the 3x3 wgrad chosen by rule (default) / never / whenever the shape is covered */
+ * 96 / 97 / 98 = Winograd form of the 3x3 wgrad chosen by rule (default) / never / whenever the shape is covered;
+ * 84 / 85 / 86 = bf16x3 form of the 3x3 wgrad (csrc/bf3_wgrad.hip) by rule (default) / never / whenever the shape is covered;
+ * 80 / 81 / 82 = bf16x3 form of the 3x3 forward / dgrad (see afd_conv3x3_weight_kinds below) */
 int afd_debug_conv_path(int mode);
 int afd_conv_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
                  int B, int Cin, int Cout, int H, int W, int ksize, int act, afd_stream_t stream);
 int afd_conv_dgrad(const float* dy, const float* w, float* dx,
                    int B, int Cin, int Cout, int H, int W, int ksize, afd_stream_t stream);
 size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ksize);
+/* which kernel afd_conv_wgrad (dbias == NULL) runs for the shape: 0 = direct implicit GEMM on the fp32 MFMA,
+ * 1 = Winograd F(3x3,2x2) on the fp32 MFMA, 2 = pixel-reduction GEMM on the bf16 MFMA with exact three-piece splits
+ * (fp32 accuracy).  For reporting (bench.py prices each launch against the peak of the instruction it issues). */
+int afd_conv_wgrad_form(int B, int Cin, int Cout, int H, int W, int ksize);
 int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias /* or NULL */,
                    int B, int Cin, int Cout, int H, int W, int ksize, int accumulate,
                    void* workspace, afd_stream_t stream);
