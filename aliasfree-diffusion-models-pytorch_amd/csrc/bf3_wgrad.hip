@@ -49,6 +49,75 @@ __device__ __forceinline__ uint32_t bf_pack(__bf16 lo, __bf16 hi) {
   return (uint32_t)__builtin_bit_cast(uint16_t, lo) | ((uint32_t)__builtin_bit_cast(uint16_t, hi) << 16);
 }
 
+// wave groups 1 .. NSG-1 hand their sums to group 0 through LDS, in a fixed order; group 0 writes the slab [split][tap][cout][cin]
+// (accumulator: row n = 4 (l >> 4) + reg, column k = l & 15)
+template <int NR, int NSG>
+__device__ __forceinline__ void wg_finish(f32x4 (&acc)[2][9], uint8_t* smem_raw, float* __restrict__ part, int split, int role, int sg,
+                                          int lane, int n0w, int k0w, int N, int K) {
+  const int l15 = lane & 15, kgl = lane >> 4;
+  if (NSG > 1) {
+    float* red = reinterpret_cast<float*>(smem_raw);                  // [role][72][64]
+#pragma unroll 1
+    for (int g = 1; g < NSG; ++g) {
+      __syncthreads();                                                 // (first round: the last tile's fragment reads are done)
+      if (sg == g) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) red[(role * 72 + (ks * 9 + t) * 4 + rg) * 64 + lane] = acc[ks][t][rg];
+      }
+      __syncthreads();
+      if (sg == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) acc[ks][t][rg] += red[(role * 72 + (ks * 9 + t) * 4 + rg) * 64 + lane];
+      }
+    }
+    if (sg != 0) return;
+  }
+  float* ps = part + (long)split * 9 * N * K;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) ps[((long)t * N + n0w + 4 * kgl + rg) * K + k0w + 16 * ks + l15] = acc[ks][t][rg];
+}
+
+// the 54 + 54 MFMAs of one 32-pixel step: units (16-channel block ks, row shift ty), B fragments one unit ahead; gb = record of
+// (piece 0, this wave's first channel block, the lane's group at row shift 0, channel l & 15), kstride = records per channel
+// block, toff[ty] = record offset of row shift ty
+__device__ __forceinline__ void wg_step(f32x4 (&acc)[2][9], const bf8 (&af)[3][3], const bf8* __restrict__ Xs, int PIECE, int gb, int kstride,
+                                        int toff0, int toff1, int toff2) {
+  bf8 bc[3], bn[3];
+  { const int o = gb + toff0; bc[0] = Xs[o]; bc[1] = Xs[PIECE + o]; bc[2] = Xs[2 * PIECE + o]; }
+#pragma unroll
+  for (int u = 0; u < 6; ++u) {                                        // unit = (channel block ks, row shift ty)
+    const int ks = u / 3, ty = u % 3;
+    if (u + 1 < 6) {
+      const int ksn = (u + 1) / 3, tyn = (u + 1) % 3;
+      const int o = gb + ksn * kstride + (tyn == 0 ? toff0 : (tyn == 1 ? toff1 : toff2));
+      bn[0] = Xs[o]; bn[1] = Xs[PIECE + o]; bn[2] = Xs[2 * PIECE + o];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {  // term-major over the three column shifts: consecutive MFMAs go to different accumulators
+      constexpr int TA[6] = {0, 1, 0, 2, 1, 0}, TB[6] = {0, 0, 1, 0, 1, 2};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+          acc[ks][ty * 3 + tx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][TA[t]], bc[TB[t]], acc[ks][ty * 3 + tx], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2];
+  }
+}
+
 template <int S, int BN, int BK>
 __global__ __launch_bounds__(512, 1) void wgrad_bf3(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
                                                     int B, int K, int N, int tiles_per_split, int ntiles) {
@@ -161,69 +230,113 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3(const float* __restrict__ x,
       // the next step's dY (or the next tile's first) in flight during the multiplies
       if (step + NSG < 4) d_fetch(tile, step + NSG); else if (tile + 1 < tend) d_fetch(tile + 1, sg);
 
-      const int gb = brec0 + b_group(step) * 16;
-      bf8 bc[3], bn[3];
-      { const int o = gb - G8 * 16; bc[0] = Xs[o]; bc[1] = Xs[PIECE + o]; bc[2] = Xs[2 * PIECE + o]; }
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {                                    // unit = (channel block ks, row shift ty)
-        const int ks = u / 3, ty = u % 3;
-        if (u + 1 < 6) {
-          const int ksn = (u + 1) / 3, tyn = (u + 1) % 3;
-          const int o = gb + ksn * NG * 16 + (tyn - 1) * G8 * 16;
-          bn[0] = Xs[o]; bn[1] = Xs[PIECE + o]; bn[2] = Xs[2 * PIECE + o];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {  // term-major over the three column shifts: consecutive MFMAs go to different accumulators
-          constexpr int TA[6] = {0, 1, 0, 2, 1, 0}, TB[6] = {0, 0, 1, 0, 1, 2};
-#pragma unroll
-          for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int tx = 0; tx < 3; ++tx)
-              acc[ks][ty * 3 + tx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tx][TA[t]], bc[TB[t]], acc[ks][ty * 3 + tx], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2];
-      }
+      wg_step(acc, af, Xs, PIECE, brec0 + b_group(step) * 16, NG * 16, -G8 * 16, 0, G8 * 16);
     }
   }
 
-  // ---- wave groups 1 .. NSG-1 hand their sums to group 0 through LDS, in a fixed order
-  if (NSG > 1) {
-    float* red = reinterpret_cast<float*>(smem_raw);                  // [role][72][64]
-#pragma unroll 1
-    for (int g = 1; g < NSG; ++g) {
-      __syncthreads();                                                 // (first round: the last tile's fragment reads are done)
-      if (sg == g) {
+  wg_finish<G::NR, NSG>(acc, smem_raw, part, split, role, sg, lane, n0 + 16 * ns, k0 + 32 * kh, N, K);
+}
+
+
+// ---- 4 x 4 maps -------------------------------------------------------------------------------------------------------------
+// An 8-pixel group is TWO rows of an image, so a row shift of one is half a group: every (image, channel) keeps FIVE
+// records per piece -- the aligned pairs (rows 0-1, 2-3: row shift 0) and the odd pairs (rows -1-0, 1-2, 3-4 with the
+// outside rows zero: shifts -1 / +1).  A 128-pixel tile = 8 whole images, a 32-pixel step = 2 of them; the column shift
+// stays inside each row of four (no neighbour loads).  One staging task = one (image, channel): 16 contiguous floats.
+template <int BN, int BK>
+__global__ __launch_bounds__(512, 1) void wgrad_bf3_s4(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                       int B, int K, int N, int tiles_per_split, int ntiles) {
+  constexpr int NR = (BN / 16) * (BK / 32), NSG = 8 / NR, NG = 40, PIECE = (BK / 16) * NG * 16, TASKS = 8 * BK;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  bf8* Xs = reinterpret_cast<bf8*>(smem_raw);                         // [piece 3][ksub BK / 16][image 8][record 5][16] records
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kgl = lane >> 4;
+  const int role = wv % NR, sg = wv / NR;
+  const int ns = role % (BN / 16), kh = role / (BN / 16);
+  const int nkb = blockIdx.y, nbk = N / BN;
+  const int n0 = (nkb % nbk) * BN, k0 = (nkb / nbk) * BK;
+  const int split = blockIdx.x;
+  const int tbeg = split * tiles_per_split, tend = min(ntiles, tbeg + tiles_per_split);
+
+  const bool has_task = tid < TASKS;
+  const int ti = tid / BK, tc = tid % BK;                              // staging task: image ti of the tile, channel tc
+  float xr[16];
+  auto x_fetch = [&](int tile) {
+    const int img = tile * 8 + ti;
+    const bool ok = has_task && img < B;
+    const float4* p = reinterpret_cast<const float4*>(x + ((long)(ok ? img : 0) * K + k0 + tc) * 16);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) red[(role * 72 + (ks * 9 + t) * 4 + rg) * 64 + lane] = acc[ks][t][rg];
-      }
-      __syncthreads();
-      if (sg == 0) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) acc[ks][t][rg] += red[(role * 72 + (ks * 9 + t) * 4 + rg) * 64 + lane];
-      }
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = ok ? p[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      xr[4 * q] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
     }
-    if (sg != 0) return;
-  }
-  // ---- epilogue: accumulator (row n = 4 (l >> 4) + reg, column k = l & 15) -> slab [split][tap][cout][cin]
-  float* ps = part + (long)split * 9 * N * K;
+  };
+  auto x_commit = [&]() {
+    if (!has_task) return;
+    __bf16 pc[3][16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bf3_split(xr[j], pc[0][j], pc[1][j], pc[2][j]);
+    const __bf16 Z = (__bf16)0.f;
+    const int rec = (((tc >> 4) * 8 + ti) * 5) * 16 + (tc & 15);       // record 0 of this (image, channel)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      bf8 a0, a1, o0, o1, o2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a0[j] = pc[p][j]; a1[j] = pc[p][8 + j]; o1[j] = pc[p][4 + j];
+        o0[j] = j < 4 ? Z : pc[p][j - 4];                              // rows (-1, 0)
+        o2[j] = j < 4 ? pc[p][12 + j] : Z;                             // rows (3, 4)
+      }
+      bf8* d = Xs + p * PIECE + rec;
+      d[0] = a0; d[16] = a1; d[32] = o0; d[48] = o1; d[64] = o2;
+    }
+  };
+
+  float dv[8];
+  const float* dyw = dy + (long)(n0 + 16 * ns + l15) * 16;
+  auto d_fetch = [&](int tile, int step) {
+    const int img = tile * 8 + 2 * step + (kgl >> 1);
+    const bool ok = img < B;
+    const float4* p = reinterpret_cast<const float4*>(dyw + (long)(ok ? img : 0) * N * 16 + (kgl & 1) * 8);
+    const float4 a = ok ? p[0] : make_float4(0.f, 0.f, 0.f, 0.f), b = ok ? p[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    dv[0] = a.x; dv[1] = a.y; dv[2] = a.z; dv[3] = a.w; dv[4] = b.x; dv[5] = b.y; dv[6] = b.z; dv[7] = b.w;
+  };
+
+  f32x4 acc[2][9];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg)
-        ps[((long)t * N + n0 + 16 * ns + 4 * kgl + rg) * K + k0 + 32 * kh + 16 * ks + l15] = acc[ks][t][rg];
-}
+    for (int t = 0; t < 9; ++t) acc[ks][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int brec0 = ((2 * kh) * NG) * 16 + l15;
 
+  if (tbeg < tend) { x_fetch(tbeg); d_fetch(tbeg, sg); }
+  for (int tile = tbeg; tile < tend; ++tile) {
+    __syncthreads();
+    x_commit();
+    __syncthreads();
+    if (tile + 1 < tend) x_fetch(tile + 1);
+#pragma unroll 1
+    for (int step = sg; step < 4; step += NSG) {
+      __bf16 pc[3][8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bf3_split(dv[j], pc[0][j], pc[1][j], pc[2][j]);
+      const __bf16 Z = (__bf16)0.f;
+      bf8 af[3][3];                                                    // [tx][piece]: dY[q+1] | dY[q] | dY[q-1] inside each row of four
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          af[1][p][j] = pc[p][j];
+          af[0][p][j] = (j & 3) == 3 ? Z : pc[p][(j + 1) & 7];
+          af[2][p][j] = (j & 3) == 0 ? Z : pc[p][(j + 7) & 7];
+        }
+      if (step + NSG < 4) d_fetch(tile, step + NSG); else if (tile + 1 < tend) d_fetch(tile + 1, sg);
+      // the lane's group: image 2 step + (kgl >> 1), row pair kgl & 1: aligned record (kgl & 1), odd records 2 + (kgl & 1) / 3 + (kgl & 1)
+      const int gb = brec0 + ((2 * step + (kgl >> 1)) * 5 + (kgl & 1)) * 16;
+      wg_step(acc, af, Xs, PIECE, gb, NG * 16, 2 * 16, 0, 3 * 16);
+    }
+  }
+  wg_finish<NR, NSG>(acc, smem_raw, part, split, role, sg, lane, n0 + 16 * ns, k0 + 32 * kh, N, K);
+}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // 1x1 convolutions / token Linear layers:  dW[n][k] = sum_p dY[n][p] X[k][p],  db[n] = sum_p dY[n][p]
@@ -347,10 +460,10 @@ void wgrad_bf3_set_mode(int m) { g_wgbf3_mode = m; }
 // plan: the number of slabs (0 = not covered / not chosen) and the tiles per split
 int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles) {
   if (g_wgbf3_mode == 1) return 0;
-  if (H != W || (W != 8 && W != 16 && W != 32)) return 0;
+  if (H != W || (W != 4 && W != 8 && W != 16 && W != 32)) return 0;
   if (Cin % 32 || Cout % 32) return 0;
   if ((long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return 0;
-  const long nt = W == 8 ? (B + 1) / 2 : (long)B * (H * W / 128);
+  const long nt = W == 4 ? (B + 7) / 8 : (W == 8 ? (B + 1) / 2 : (long)B * (H * W / 128));
   const int BN = Cout % 64 == 0 ? 64 : 32, BK = Cin % 64 == 0 ? 64 : 32;
   const long blocks = (long)(Cout / BN) * (Cin / BK);
   static const long target = [] { const char* e = getenv("AFD_WGB_TARGET"); return e ? atol(e) : 256L; }();   // tuning hook
@@ -377,6 +490,20 @@ static void wgrad_bf3_launch_t(const float* x, const float* dy, float* part, int
                      part, B, Cin, Cout, tps, nt);
 }
 
+template <int BN, int BK>
+static void wgrad_bf3_s4_launch_t(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int tps, int nt, int splits,
+                                  hipStream_t s) {
+  constexpr int NR = (BN / 16) * (BK / 32);
+  const size_t lds = std::max((size_t)3 * (BK / 16) * 40 * 16 * 16, 8 / NR > 1 ? sizeof(float) * NR * 72 * 64 : (size_t)0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf3_s4<BN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_bf3_s4<BN, BK>), dim3((unsigned)splits, (unsigned)((Cout / BN) * (Cin / BK))), dim3(512), lds, s, x, dy, part, B,
+                     Cin, Cout, tps, nt);
+}
+
 // writes `slabs` partial [9][Cout][Cin] slabs into part; the caller reduces them (wgrad_reduce)
 int wgrad_bf3(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s) {
   int tps, nt;
@@ -388,7 +515,11 @@ int wgrad_bf3(const float* x, const float* dy, float* part, int B, int Cin, int 
   else if (n64) wgrad_bf3_launch_t<S_, 64, 32>(x, dy, part, B, Cin, Cout, tps, nt, splits, s);            \
   else if (k64) wgrad_bf3_launch_t<S_, 32, 64>(x, dy, part, B, Cin, Cout, tps, nt, splits, s);            \
   else wgrad_bf3_launch_t<S_, 32, 32>(x, dy, part, B, Cin, Cout, tps, nt, splits, s)
-  if (W == 32) { AFD_WGB(32); } else if (W == 16) { AFD_WGB(16); } else { AFD_WGB(8); }
+  if (W == 32) { AFD_WGB(32); } else if (W == 16) { AFD_WGB(16); } else if (W == 8) { AFD_WGB(8); }
+  else if (n64 && k64) wgrad_bf3_s4_launch_t<64, 64>(x, dy, part, B, Cin, Cout, tps, nt, splits, s);
+  else if (n64) wgrad_bf3_s4_launch_t<64, 32>(x, dy, part, B, Cin, Cout, tps, nt, splits, s);
+  else if (k64) wgrad_bf3_s4_launch_t<32, 64>(x, dy, part, B, Cin, Cout, tps, nt, splits, s);
+  else wgrad_bf3_s4_launch_t<32, 32>(x, dy, part, B, Cin, Cout, tps, nt, splits, s);
 #undef AFD_WGB
   return splits;
 }
