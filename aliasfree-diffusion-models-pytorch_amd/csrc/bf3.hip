@@ -11,15 +11,17 @@
 // per staging (one element feeds 9 taps x all output channels of the workgroup), and the splitting (vector pipe) overlaps
 // the multiplies (matrix pipe).  Measured max error 1.6e-7 of sum|a b| on this scheme (attention kernels, round 1).
 //
-//   bf3_weights    Wp[piece][tap][k/16][(k/8)&1][n][8 bf16]: 16-byte records = the A fragment of one lane
-//                  (v_mfma_f32_32x32x16_bf16: lane (row n, half) holds k = 8 half + j); forward: n = cout, k = cin;
-//                  dgrad: n = cin, k = cout, taps rotated by 180 degrees -- ONE main kernel serves both passes.
+//   bf3_weights    Wp[piece][tap][k/8][n][8 bf16]: 16-byte records = the A fragment of one lane
+//                  (v_mfma_f32_16x16x32_bf16: lane (row n = l & 15, group l >> 4) holds k = 8 (l >> 4) + j); forward:
+//                  n = cout, k = cin; dgrad: n = cin, k = cout, taps rotated by 180 degrees -- ONE main kernel serves
+//                  both passes.  (16x16x32, not 32x32x16: a dense bf16 MFMA loop is power-limited on this chip and the
+//                  smaller shape holds the higher clock -- 96 -> 77 us on 128->128 @16x16 from the shape change alone.)
 //   conv_bf3       a workgroup owns NBLK x 32 output channels x 128 output pixels (whole rows of one image, or whole
 //                  images).  Per chunk of 32 input channels the haloed input pixels go global -> registers -> split ->
 //                  LDS as Xp[piece][k/8][pixel][8 bf16] (the next chunk's loads in flight during the multiplies); a
 //                  B fragment is one ds_read_b128 at (pixel + tap offset), consecutive lanes = consecutive pixels:
 //                  conflict-free.  A fragments come straight from global memory / L2 (consecutive lanes = consecutive
-//                  16-byte records), two (tap, k-step) groups ahead.  6 MFMAs per (tap, k-step, 32-pixel block).
+//                  16-byte records), one or two (tap, chunk) groups ahead.  6 MFMAs per (tap, chunk, 16 x 16 block).
 #include <algorithm>
 #include <cstdint>
 #include "common.h"

@@ -526,8 +526,10 @@ int wgrad_bf3(const float* x, const float* dy, float* part, int B, int Cin, int 
 
 
 // 1x1 plan: slabs (0 = not covered / not chosen); fills the steps per split, the roles per workgroup and NT
+static int g_pwbf3_mode = 0;       // afd_debug_conv_path 88 / 89: the 1x1 form by the rule / off
+void pw_wgrad_bf3_set_mode(int m) { g_pwbf3_mode = m; }
 int pw_wgrad_bf3_plan(int B, int Cin, int Cout, int L, int* sps, int* nsteps, int* nr, int* nt) {
-  if (g_wgbf3_mode == 1) return 0;
+  if (g_wgbf3_mode == 1 || g_pwbf3_mode == 1) return 0;
   if (Cin % 32 || Cout % 32 || L % 32) return 0;
   if ((long)B * L * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return 0;
   const int NT = Cout % 48 == 0 ? 3 : 2;

@@ -810,6 +810,7 @@ int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, in
 int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles);
 int wgrad_bf3(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
 void wgrad_bf3_set_mode(int m);
+void pw_wgrad_bf3_set_mode(int m);
 int pw_wgrad_bf3_plan(int B, int Cin, int Cout, int L, int* sps, int* nsteps, int* nr, int* nt);
 int pw_wgrad_bf3(const float* x, const float* dy, float* part, float* bias_part, int B, int Cin, int Cout, int L, hipStream_t s);
 int wgrad_wino(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
@@ -921,6 +922,7 @@ using namespace afd;
 extern "C" {
 
 int afd_debug_conv_path(int mode) {
+  if (mode >= 88 && mode <= 89) { pw_wgrad_bf3_set_mode(mode - 88); return AFD_OK; }   // bf16x3 1x1 wgrad: 88 = by rule (default), 89 = off
   if (mode >= 84 && mode <= 86) { wgrad_bf3_set_mode(mode - 84); return AFD_OK; }   // bf16x3 3x3 wgrad: 84 = by rule (default), 85 = off, 86 = wherever covered
   if (mode >= 80 && mode <= 82) { bf3_set_mode(mode - 80); return AFD_OK; }   // direct bf16x3 3x3 kernel: 80 = by rule (default), 81 = off, 82 = wherever covered
   if (mode >= 8 && mode <= 10) { pw_set_mode(mode - 8); return AFD_OK; }     // 1x1 streaming kernel: 8 = by rule (default), 9 = off, 10 = forced

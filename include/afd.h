@@ -113,7 +113,8 @@ int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, in
  * 8 / 9 / 10 = 1x1 streaming kernel chosen by the measured rule (default) / never / whenever the shape is covered;
  * 32 / 33 / 34 = wgrad workgroups of 4 waves / 8 waves / chosen per layer (default);
  * 96 / 97 / 98 = Winograd form of the 3x3 wgrad chosen by rule (default) / never / whenever the shape is covered;
- * 84 / 85 / 86 = bf16x3 form of the 3x3 wgrad (csrc/bf3_wgrad.hip) by rule (default) / never / whenever the shape is covered;
+ * 84 / 85 / 86 = bf16x3 form of the 3x3 wgrad (csrc/bf3_wgrad.hip) by rule (default) / never / whenever the shape is covered
+ *                (85 also switches the 1x1 form off); 88 / 89 = bf16x3 form of the 1x1 wgrad by rule (default) / never;
  * 80 / 81 / 82 = bf16x3 form of the 3x3 forward / dgrad (see afd_conv3x3_weight_kinds below) */
 int afd_debug_conv_path(int mode);
 int afd_conv_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,

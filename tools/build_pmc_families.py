@@ -53,7 +53,7 @@ groups = {"attn_bwd": {"attn_bwd_dq_k", "attn_bwd_dkv_k", "attn_bwd_dq_mfma8", "
           "groupnorm1_stats": {"gn_fwd_reg", "gn_fwd_loop"}, "groupnorm1_bwd_apply": {"gn_bwd_apply"},
           "tok_head_fwd": {"tok_head_fwd", "tok_head_fwd_wide"}, "tok_tail_fwd": {"tok_tail_fwd", "tok_tail_fwd_wide"},
           "tok_tail_bwd": {"tok_tail_bwd", "tok_tail_bwd_wide"}, "tok_head_bwd": {"tok_head_bwd", "tok_head_bwd_wide"},
-          "linear_wgrad": {"conv_wgrad_mfma"}, "layernorm_params": {"ln_c_bwd_plane"}}
+          "linear_wgrad": {"conv_wgrad_mfma", "pw_wgrad_bf3"}, "layernorm_params": {"ln_c_bwd_plane"}}
 for fam, ks in groups.items():
     d = summarise(whole, steps, ks)
     d["source"] = f"profiles/pmc_families.json: {src}, whole train step (bench.py --no-graph), kernels {sorted(ks)}"
