@@ -457,6 +457,19 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_bf3(const float* __restrict__
 static int g_wgbf3_mode = 0;       // afd_debug_conv_path 84 / 85 / 86: by the rule / off / wherever the shape is covered
 void wgrad_bf3_set_mode(int m) { g_wgbf3_mode = m; }
 
+// the (output, input) channel block of a workgroup: 64 x 64 where the layer has >= 1024 (tile, block) work items -- twice
+// the operand reuse per MFMA, 18 % faster on the large layers -- else 32 x 32: four times the blocks per split, so a quarter
+// of the splits and of the slab bytes, 15-30 % faster on the 4x4 maps and the thin 8x8 layers (tools/wgrad_bench.py,
+// AFD_WGB_TILE=32 / 64 forces one size)
+static void wgrad_bf3_tile(int Cin, int Cout, long nt, int* bn, int* bk) {
+  static const int force = [] { const char* e = getenv("AFD_WGB_TILE"); return e ? atoi(e) : 0; }();
+  const bool can = Cout % 64 == 0 && Cin % 64 == 0;
+  const bool big = force ? force >= 64 : nt * (Cout / 64) * (Cin / 64) >= 1024;
+  if (can && big) { *bn = 64; *bk = 64; return; }
+  *bn = (Cout % 64 == 0 && Cin % 64 && (force ? force >= 64 : true)) ? 64 : 32;   // mixed widths keep the 64-wide side
+  *bk = (Cin % 64 == 0 && Cout % 64 && (force ? force >= 64 : true)) ? 64 : 32;
+}
+
 // plan: the number of slabs (0 = not covered / not chosen) and the tiles per split
 int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles) {
   if (g_wgbf3_mode == 1) return 0;
@@ -464,7 +477,8 @@ int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles
   if (Cin % 32 || Cout % 32) return 0;
   if ((long)B * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return 0;
   const long nt = W == 4 ? (B + 7) / 8 : (W == 8 ? (B + 1) / 2 : (long)B * (H * W / 128));
-  const int BN = Cout % 64 == 0 ? 64 : 32, BK = Cin % 64 == 0 ? 64 : 32;
+  int BN, BK;
+  wgrad_bf3_tile(Cin, Cout, W == 4 ? (B + 7) / 8 : (W == 8 ? (B + 1) / 2 : (long)B * (H * W / 128)), &BN, &BK);
   const long blocks = (long)(Cout / BN) * (Cin / BK);
   static const long target = [] { const char* e = getenv("AFD_WGB_TARGET"); return e ? atol(e) : 256L; }();   // tuning hook
   long s = target / blocks;
@@ -509,7 +523,9 @@ int wgrad_bf3(const float* x, const float* dy, float* part, int B, int Cin, int 
   int tps, nt;
   const int splits = wgrad_bf3_plan(B, Cin, Cout, H, W, &tps, &nt);
   if (!splits) return 0;
-  const bool n64 = Cout % 64 == 0, k64 = Cin % 64 == 0;
+  int bn_, bk_;
+  wgrad_bf3_tile(Cin, Cout, nt, &bn_, &bk_);
+  const bool n64 = bn_ == 64, k64 = bk_ == 64;
 #define AFD_WGB(S_)                                                                                       \
   if (n64 && k64) wgrad_bf3_launch_t<S_, 64, 64>(x, dy, part, B, Cin, Cout, tps, nt, splits, s);          \
   else if (n64) wgrad_bf3_launch_t<S_, 64, 32>(x, dy, part, B, Cin, Cout, tps, nt, splits, s);            \
