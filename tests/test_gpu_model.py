@@ -233,6 +233,48 @@ def test_overlapped_weight_gradients_are_bitwise_equal(A):
     assert torch.equal(outs[1], outs[2])
 
 
+def test_full_batch_step_bf16x3_kernels_agree_with_fp32_kernels(A):
+    """BASELINE size (Config D, B = 256): one forward + backward of the whole net with every layer on the kernels the rule
+    picks (bf16x3 forward / dgrad / 3x3 and 1x1 weight gradients on the matrix cores) against the same step with those
+    switched off (fp32 Winograd / direct kernels, an independent algorithm): loss and every parameter gradient agree far
+    inside the 1e-5 contract.  The rule must really have picked the bf16x3 forms at this size."""
+    afdm, dev = A
+    from afdm import ops
+    L = afdm.lib()
+    assert L.afd_conv3x3_weight_kinds(256, 128, 128, 16, 16) == 3 and L.afd_conv_wgrad_form(256, 128, 128, 16, 16, 3) == 2
+    assert L.afd_conv_wgrad_form(256, 32, 96, 32, 32, 1) == 2
+    afdm.set_seed(42)
+    model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device=dev, variant=3).to(dev)
+    diff = afdm.Diffusion(noise_steps=1000, img_size=32, device=dev)
+    g = torch.Generator().manual_seed(11)
+    images = torch.randn(256, 3, 32, 32, generator=g).to(dev)
+    t = torch.randint(1, 1000, (256,), generator=g)
+    eps = torch.randn(256, 3, 32, 32, generator=g).to(dev)
+    outs = []
+    try:
+        for modes in ((80, 84, 88), (81, 85, 89)):
+            for m in modes:
+                L.afd_debug_conv_path(m)
+            model.zero_grad(set_to_none=True)
+            x_t, _ = diff.noise_images(images, t.to(dev), eps=eps)
+            loss = ops.mse_loss(eps, model(x_t, t.to(dev)))
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((loss.item(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    finally:
+        for m in (80, 84, 88):
+            L.afd_debug_conv_path(m)
+    assert abs(outs[0][0] - outs[1][0]) <= 2e-6 * abs(outs[1][0])
+    assert outs[0][1].keys() == outs[1][1].keys() and len(outs[0][1]) > 150
+    worst = 0.0
+    for n in outs[0][1]:
+        a, b = outs[0][1][n].double(), outs[1][1][n].double()
+        if b.norm() > 0:
+            worst = max(worst, ((a - b).norm() / b.norm()).item())
+            check("full-batch step: bf16x3 vs fp32 kernels, parameter gradients", outs[0][1][n].cpu(), outs[1][1][n].cpu(), 1e-5, n)
+    assert worst < 1e-5
+
+
 def test_graph_replay_equals_eager(A):
     afdm, dev = A
     g = load_golden("train_step.npz")
