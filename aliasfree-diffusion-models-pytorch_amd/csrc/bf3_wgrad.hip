@@ -453,6 +453,69 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_bf3(const float* __restrict__
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The network's first layer (3 input channels): dW[n][c][ty][tx] is 27 numbers per output channel, the layer reads 12 B of
+// x per 4 N B of dY -- memory-bound, and the LAST weight gradient of a step (nothing left to overlap with).  Vector FMAs:
+// a workgroup (8 waves) takes whole images; the image sits zero-haloed in LDS, lane = pixel, wave w owns 4 output channels
+// x 27 taps = 108 running sums per lane; wave-reduced once at the end, one slab per workgroup (fixed order, no atomics).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(512, 1) void wgrad_cin3(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                     int B, int N) {
+  constexpr int RS = S + 3, PL = (S + 2) * RS;                         // LDS row stride, plane size (odd stride: rows spread over the banks)
+  __shared__ float Xs[3 * PL];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n0 = blockIdx.y * 32 + 4 * wv;
+  for (int i = tid; i < 3 * PL; i += 512) Xs[i] = 0.f;                 // the halo stays zero
+  float acc[4][27];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[j][t] = 0.f;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();                                                   // the previous image's reads are done (first: the zero fill)
+    for (int i = tid; i < 3 * S * S; i += 512) {
+      const int c = i / (S * S), rem = i - c * S * S, r = rem / S, col = rem - r * S;
+      Xs[c * PL + (r + 1) * RS + col + 1] = x[((long)b * 3 + c) * S * S + rem];
+    }
+    __syncthreads();
+    const float* dyb = dy + ((long)b * N + n0) * S * S;
+    float dn[4];                                                       // the next iteration's dY in flight during the FMAs
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dn[j] = dyb[(long)j * S * S + lane];
+#pragma unroll 1
+    for (int p = lane; p < S * S; p += 64) {
+      const int r = p / S, col = p - r * S;
+      float d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = dn[j];
+      if (p + 64 < S * S) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dn[j] = dyb[(long)j * S * S + p + 64];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) {
+            const float xv = Xs[c * PL + (r + ty) * RS + col + tx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j][(ty * 3 + tx) * 3 + c] = fmaf(d[j], xv, acc[j][(ty * 3 + tx) * 3 + c]);
+          }
+    }
+  }
+  float* ps = part + (long)blockIdx.x * 27 * N;                         // slab [tap][cout][cin = 3]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const float v = wave_sum_to_lane63(acc[j][t]);
+      if (lane == 63) ps[((long)(t / 3) * N + n0 + j) * 3 + (t % 3)] = v;
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static int g_wgbf3_mode = 0;       // afd_debug_conv_path 84 / 85 / 86: by the rule / off / wherever the shape is covered
 void wgrad_bf3_set_mode(int m) { g_wgbf3_mode = m; }
@@ -573,6 +636,23 @@ int pw_wgrad_bf3(const float* x, const float* dy, float* part, float* bias_part,
   if (NT == 3) hipLaunchKernelGGL(pw_wgrad_bf3<3>, grid, dim3(512), lds, s, x, dy, part, bias_part, B, Cin, Cout, L, sps, st, NR);
   else hipLaunchKernelGGL(pw_wgrad_bf3<2>, grid, dim3(512), lds, s, x, dy, part, bias_part, B, Cin, Cout, L, sps, st, NR);
   return splits;
+}
+
+
+// first-layer form: slabs (0 = not covered)
+int wgrad_cin3_plan(int B, int Cin, int Cout, int H, int W) {
+  if (g_wgbf3_mode == 1) return 0;
+  if (Cin != 3 || Cout % 32 || H != W || (W != 16 && W != 32 && W != 64)) return 0;
+  return B < 256 ? B : 256;
+}
+int wgrad_cin3(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s) {
+  const int slabs = wgrad_cin3_plan(B, Cin, Cout, H, W);
+  if (!slabs) return 0;
+  const dim3 grid((unsigned)slabs, (unsigned)(Cout / 32));
+  if (W == 64) hipLaunchKernelGGL(wgrad_cin3<64>, grid, dim3(512), 0, s, x, dy, part, B, Cout);
+  else if (W == 32) hipLaunchKernelGGL(wgrad_cin3<32>, grid, dim3(512), 0, s, x, dy, part, B, Cout);
+  else hipLaunchKernelGGL(wgrad_cin3<16>, grid, dim3(512), 0, s, x, dy, part, B, Cout);
+  return slabs;
 }
 
 }  // namespace afd

@@ -59,6 +59,21 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// the wave's sum in lane 63 only, on the vector pipe alone (DPP row shifts + row broadcasts, 6 instructions, no LDS
+// round trips): for kernels that reduce MANY registers at once (wave_sum's cross-half steps are ds_bpermute)
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+#define AFD_DPP_ADD(CTRL, ROWMASK)                                                                                          \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, true))
+  AFD_DPP_ADD(0x111, 0xf);       // row_shr:1
+  AFD_DPP_ADD(0x112, 0xf);       // row_shr:2
+  AFD_DPP_ADD(0x114, 0xf);       // row_shr:4  (lane i of a row now holds the sum of lanes max(0, i-7) .. i)
+  AFD_DPP_ADD(0x118, 0xf);       // row_shr:8  (lane 15 of every row: the row's sum)
+  AFD_DPP_ADD(0x142, 0xa);       // row_bcast:15 into rows 1 and 3
+  AFD_DPP_ADD(0x143, 0xc);       // row_bcast:31 into rows 2 and 3
+#undef AFD_DPP_ADD
+  return v;
+}
+
 // block-wide sum for blockDim.x <= 1024 (all threads get the result); `red` >= 16 floats of LDS
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);

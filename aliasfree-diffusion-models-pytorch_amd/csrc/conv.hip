@@ -810,6 +810,13 @@ int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, in
 int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles);
 int wgrad_bf3(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
 void wgrad_bf3_set_mode(int m);
+// ends.hip: the 1x1 output layer and its dgrad as streaming vector kernels
+bool ends_fwd(const float* x, const float* w, const float* bias, const float* res, float* y, int B, int Cin, int Cout, int H, int W,
+              int ksize, int act, hipStream_t s);
+bool ends_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int H, int W, int ksize, hipStream_t s);
+void ends_set_mode(int m);
+int wgrad_cin3_plan(int B, int Cin, int Cout, int H, int W);
+int wgrad_cin3(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
 void pw_wgrad_bf3_set_mode(int m);
 int pw_wgrad_bf3_plan(int B, int Cin, int Cout, int L, int* sps, int* nsteps, int* nr, int* nt);
 int pw_wgrad_bf3(const float* x, const float* dy, float* part, float* bias_part, int B, int Cin, int Cout, int L, hipStream_t s);
@@ -922,6 +929,7 @@ using namespace afd;
 extern "C" {
 
 int afd_debug_conv_path(int mode) {
+  if (mode >= 92 && mode <= 93) { ends_set_mode(mode - 92); return AFD_OK; }   // output-layer streaming kernels: 92 = by rule (default), 93 = off
   if (mode >= 88 && mode <= 89) { pw_wgrad_bf3_set_mode(mode - 88); return AFD_OK; }   // bf16x3 1x1 wgrad: 88 = by rule (default), 89 = off
   if (mode >= 84 && mode <= 86) { wgrad_bf3_set_mode(mode - 84); return AFD_OK; }   // bf16x3 3x3 wgrad: 84 = by rule (default), 85 = off, 86 = wherever covered
   if (mode >= 80 && mode <= 82) { bf3_set_mode(mode - 80); return AFD_OK; }   // direct bf16x3 3x3 kernel: 80 = by rule (default), 81 = off, 82 = wherever covered
@@ -941,6 +949,7 @@ int afd_conv_fwd(const float* x, const float* w, const float* bias, const float*
   AFD_REQUIRE(ksize == 1 || ksize == 3, "afd_conv_fwd: ksize %d not in {1,3}", ksize);
   AFD_REQUIRE(act == 0 || act == 1, "afd_conv_fwd: act must be 0 or 1");
   hipStream_t s = as_stream(st);
+  if (ends_fwd(x, w, bias, res, y, B, Cin, Cout, H, W, ksize, act, s)) return check_launch("afd_conv_fwd");
   if (ksize == 1 && pw_launch(x, w, bias, res, y, B, Cin, Cout, H * W, act, false, s)) return check_launch("afd_conv_fwd");
   int rc = -1;
   if (use_mfma(Cin, Cout, H, W, 128))
@@ -958,6 +967,7 @@ int afd_conv_dgrad(const float* dy, const float* w, float* dx, int B, int Cin, i
   AFD_REQUIRE(dy && w && dx && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "afd_conv_dgrad: bad argument");
   AFD_REQUIRE(ksize == 1 || ksize == 3, "afd_conv_dgrad: ksize %d not in {1,3}", ksize);
   hipStream_t s = as_stream(st);
+  if (ends_dgrad(dy, w, dx, B, Cin, Cout, H, W, ksize, s)) return check_launch("afd_conv_dgrad");
   if (ksize == 1 && pw_launch(dy, w, nullptr, nullptr, dx, B, Cout, Cin, H * W, 0, true, s)) return check_launch("afd_conv_dgrad");
   int rc = -1;
   if (use_mfma(Cout, Cin, H, W, 128))     // reduction over Cout, output channels = Cin
@@ -1029,6 +1039,8 @@ size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, in
     if (ws > slabs) slabs = ws;
     const size_t wb = (size_t)wgrad_bf3_plan(B, Cin, Cout, H, W, &cps, &nch);
     if (wb > slabs) slabs = wb;
+    const size_t wc = (size_t)wgrad_cin3_plan(B, Cin, Cout, H, W);
+    if (wc > slabs) slabs = wc;
   }
   const size_t need = slabs * ((size_t)Cout * Cin * ksize * ksize + Cout);
   const size_t direct = (size_t)B * Cout;
@@ -1041,6 +1053,7 @@ int afd_conv_wgrad_form(int B, int Cin, int Cout, int H, int W, int ksize) {
   if (ksize == 1) return pw_wgrad_bf3_plan(B, Cin, Cout, H * W, &a, &b, &c, &d) ? 2 : 0;
   if (ksize != 3) return 0;
   if (wgrad_bf3_plan(B, Cin, Cout, H, W, &a, &b)) return 2;
+  if (wgrad_cin3_plan(B, Cin, Cout, H, W)) return 3;
   return wgrad_wino_plan(B, Cin, Cout, H, W, &a, &b, &c, &d) ? 1 : 0;
 }
 
@@ -1054,6 +1067,7 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
   if (ksize == 3 && !dbias && workspace) {                               // bf16x3 form on the matrix pipe, else Winograd F(3x3, 2x2): 16 multiplies per tile instead of 36
     float* part = static_cast<float*>(workspace);
     int slabs = wgrad_bf3(x, dy, part, B, Cin, Cout, H, W, s);
+    if (!slabs) slabs = wgrad_cin3(x, dy, part, B, Cin, Cout, H, W, s);
     if (!slabs) slabs = wgrad_wino(x, dy, part, B, Cin, Cout, H, W, s);
     if (slabs) {
       const long n = (long)Cout * Cin * 9;

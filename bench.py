@@ -270,7 +270,7 @@ def conv_layer_times(L, s, dev, B, ci, co, S, reps=5):
         td = ev_time(lambda: L.afd_conv_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), B, ci, co, S, S, 3, s), reps)
     tw = ev_time(lambda: L.afd_conv_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, B, ci, co, S, S, 3, 0, ws.data_ptr(), s), reps)
     form = lambda n, bit: "direct" if not n else ("bf3" if kinds & bit else "wino")
-    return tf, td, tw, form(nf, 1), form(nd, 2), ("direct", "wino", "bf3")[L.afd_conv_wgrad_form(B, ci, co, S, S, 3)]
+    return tf, td, tw, form(nf, 1), form(nd, 2), ("direct", "wino", "bf3", "direct")[L.afd_conv_wgrad_form(B, ci, co, S, S, 3)]
 
 
 def pmc_traffic(family, launches):

@@ -115,7 +115,9 @@ int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, in
  * 96 / 97 / 98 = Winograd form of the 3x3 wgrad chosen by rule (default) / never / whenever the shape is covered;
  * 84 / 85 / 86 = bf16x3 form of the 3x3 wgrad (csrc/bf3_wgrad.hip) by rule (default) / never / whenever the shape is covered
  *                (85 also switches the 1x1 form off); 88 / 89 = bf16x3 form of the 1x1 wgrad by rule (default) / never;
- * 80 / 81 / 82 = bf16x3 form of the 3x3 forward / dgrad (see afd_conv3x3_weight_kinds below) */
+ * 80 / 81 / 82 = bf16x3 form of the 3x3 forward / dgrad (see afd_conv3x3_weight_kinds below);
+ * 92 / 93 = streaming vector kernels for the 1x1 output layer (<= 4 output channels) and its dgrad (csrc/ends.hip) by rule
+ *           (default) / never */
 int afd_debug_conv_path(int mode);
 int afd_conv_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
                  int B, int Cin, int Cout, int H, int W, int ksize, int act, afd_stream_t stream);
@@ -124,7 +126,7 @@ int afd_conv_dgrad(const float* dy, const float* w, float* dx,
 size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ksize);
 /* which kernel afd_conv_wgrad (dbias == NULL) runs for the shape: 0 = direct implicit GEMM on the fp32 MFMA,
  * 1 = Winograd F(3x3,2x2) on the fp32 MFMA, 2 = pixel-reduction GEMM on the bf16 MFMA with exact three-piece splits
- * (fp32 accuracy).  For reporting (bench.py prices each launch against the peak of the instruction it issues). */
+ * (fp32 accuracy), 3 = the first layer's vector-FMA form (3 input channels: memory-bound).  For reporting (bench.py prices each launch against the peak of the instruction it issues). */
 int afd_conv_wgrad_form(int B, int Cin, int Cout, int H, int W, int ksize);
 int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias /* or NULL */,
                    int B, int Cin, int Cout, int H, int W, int ksize, int accumulate,

@@ -239,7 +239,8 @@ CONV_CASES = [
     (1, 256, 128, 4, 4, 3, False, False),     # one image: 16 of 128 pixels live
     (2, 12, 40, 8, 8, 3, False, False),       # K not a multiple of the chunk, N not a multiple of 32
     (2, 16, 24, 6, 10, 3, False, False),      # plane the tiler cannot cut -> direct path
-    (2, 32, 3, 32, 32, 1, True, False),       # outc: 1x1 + bias, direct (Cout < 8)
+    (2, 32, 3, 32, 32, 1, True, False),       # outc: 1x1 + bias (Cout < 8): the streaming vector kernels, fwd and dgrad
+    (3, 64, 1, 16, 16, 1, True, False),       # outc of the 1-channel configs
     (2, 32, 96, 16, 16, 1, True, False),      # in_proj as 1x1
     (3, 64, 64, 8, 8, 1, True, True),         # out_proj + residual
     (2, 128, 128, 4, 4, 1, True, True),
@@ -258,11 +259,11 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "bf3", "nobf3", "wgbf3", "nowgbf3", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "winosk", "nowino", "wgwino", "nowgwino"])
+@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "bf3", "nobf3", "wgbf3", "nowgbf3", "noends", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "winosk", "nowino", "wgwino", "nowgwino"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[5]}" for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(A, case, path):
     afdm, ops, dev = A
-    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10, "bf3": 82, "nobf3": 81, "wgbf3": 86, "nowgbf3": 85,
+    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10, "bf3": 82, "nobf3": 81, "wgbf3": 86, "nowgbf3": 85, "noends": 93,
                                         "wino64x64": 66, "wino32x64": 67, "wino64x32": 68, "wino32x32": 69, "winosk": 70, "nowino": 65, "wgwino": 98, "nowgwino": 97}[path])
     try:
         _conv_case(ops, dev, case)
@@ -272,6 +273,7 @@ def test_conv_fwd_dgrad_wgrad(A, case, path):
         afdm.lib().afd_debug_conv_path(8)
         afdm.lib().afd_debug_conv_path(80)
         afdm.lib().afd_debug_conv_path(84)
+        afdm.lib().afd_debug_conv_path(92)
         afdm.lib().afd_debug_conv_path(64)
         afdm.lib().afd_debug_conv_path(96)
 

@@ -1,0 +1,19 @@
+"""One 256-image sampling job: one batch on one stream vs the same images split over 2 / 4 streams (device time per denoise step)."""
+import sys, os, math, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, afdm
+dev = torch.device("cuda:0")
+F_SET = {"kernel_size": 3, "kaiser_beta": 2, "omega_c_down": math.pi / 2, "omega_c_up": math.pi / 2}
+afdm.set_seed(42)
+model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=F_SET, device=dev, variant=3).to(dev)
+T = 101
+diff = afdm.Diffusion(noise_steps=T, img_size=32, device=dev)
+n = 256
+for tag, fn in (("1 x 256", lambda: diff.sample(model, n=n, image_channels=3)),
+                ("2 x 128", lambda: diff.sample_concurrent(model, n=n, image_channels=3, batch=128, streams=2)),
+                ("4 x 64", lambda: diff.sample_concurrent(model, n=n, image_channels=3, batch=64, streams=4)),
+                ("3 x 86", lambda: diff.sample_concurrent(model, n=n, image_channels=3, batch=86, streams=3))):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{tag}: {dt / (T - 1) * 1e3:.3f} ms per denoise step of 256 images -> {n / (dt / (T - 1) * 999):.1f} img/s at T=1000", flush=True)
