@@ -38,6 +38,41 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
         L.afd_conv_fwd(1, 1, None, None, 1, 1, 8, 8, 4, 4, 5, 0, None)
 
 
+def test_conv_dispatch_rules_are_consistent_on_the_host():
+    """The library's per-shape kernel choice (host code only): the bf16x3 forms take the BASELINE layers by rule, small
+    batches and uncovered shapes stay on the fp32 kernels, every chosen form has a workspace to live in, and the debug
+    switches turn each form off and on again."""
+    import afdm
+    L = afdm.lib()
+    layers = [(3, 32, 32), (32, 32, 32), (64, 64, 32), (64, 32, 32), (128, 128, 16), (64, 128, 8), (256, 256, 8), (64, 64, 8),
+              (128, 128, 4), (256, 256, 4), (24, 40, 8)]
+    for (ci, co, S) in layers:
+        for B in (1, 4, 16, 256):
+            kinds = L.afd_conv3x3_weight_kinds(B, ci, co, S, S)
+            assert 0 <= kinds <= 3
+            for bit, dgrad in ((1, 0), (2, 1)):
+                if kinds & bit:                                   # a bf16x3 pass keeps its split weights in the shared workspace
+                    assert L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, dgrad) >= 54 * ci * co
+            form = L.afd_conv_wgrad_form(B, ci, co, S, S, 3)
+            assert form in (0, 1, 2, 3)
+            assert L.afd_conv_wgrad_workspace_bytes(B, ci, co, S, S, 3) >= 4 * co * ci * 9
+    assert L.afd_conv3x3_weight_kinds(256, 128, 128, 16, 16) == 3 and L.afd_conv3x3_weight_kinds(4, 128, 128, 16, 16) == 0
+    assert L.afd_conv3x3_weight_kinds(256, 128, 128, 4, 4) == 0 and L.afd_conv3x3_weight_kinds(256, 24, 40, 8, 8) == 0
+    assert L.afd_conv_wgrad_form(256, 128, 128, 16, 16, 3) == 2 and L.afd_conv_wgrad_form(256, 128, 128, 4, 4, 3) == 2
+    assert L.afd_conv_wgrad_form(256, 3, 32, 32, 32, 3) == 3 and L.afd_conv_wgrad_form(256, 24, 40, 8, 8, 3) == 0
+    assert L.afd_conv_wgrad_form(256, 32, 96, 32, 32, 1) == 2 and L.afd_conv_wgrad_form(256, 32, 3, 32, 32, 1) == 0
+    try:
+        L.afd_debug_conv_path(81); L.afd_debug_conv_path(85)
+        assert L.afd_conv3x3_weight_kinds(256, 128, 128, 16, 16) == 0
+        assert L.afd_conv_wgrad_form(256, 128, 128, 16, 16, 3) == 1 and L.afd_conv_wgrad_form(256, 32, 96, 32, 32, 1) == 0
+        assert L.afd_conv3x3_wino_workspace_bytes(256, 128, 128, 16, 16, 0) > 0        # the Winograd kernels take over
+        L.afd_debug_conv_path(82)
+        assert L.afd_conv3x3_weight_kinds(4, 128, 128, 16, 16) == 3                    # forced wherever the shape is covered
+    finally:
+        L.afd_debug_conv_path(80); L.afd_debug_conv_path(84); L.afd_debug_conv_path(88)
+    assert L.afd_conv3x3_weight_kinds(256, 128, 128, 16, 16) == 3
+
+
 def test_filter_design_in_the_library_is_bit_exact_vs_reference():
     import afdm
     g = load_golden("filters.npz")
