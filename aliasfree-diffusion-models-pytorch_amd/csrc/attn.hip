@@ -331,11 +331,13 @@ template <int D, int R> static void launch_dkv(const float* qkv, const float* d_
   else hipLaunchKernelGGL((attn_bwd_dkv_k<D, R, 256>), grid, block, 0, s, qkv, d_o, lse, delta, dqkv, heads, L, sc);
 }
 
-namespace afd {   // attn_mfma.hip: d = 8 passes with the d-contractions on the matrix cores
+namespace afd {   // attn_mfma.hip: d = 8 / 16 passes with the d-contractions on the matrix cores
 bool attn_mfma8_ok(int d, int L);
-void attn_mfma8_fwd(const float* qkv, float* o, float* lse, int B, int heads, int L, float sc, hipStream_t s);
-void attn_mfma8_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta,
-                    int B, int heads, int L, float sc, hipStream_t s);
+void attn_mfma8_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d, int L, float sc, hipStream_t s);
+void attn_mfma8_bwd_dq(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta,
+                       int B, int heads, int d, int L, float sc, hipStream_t s);
+void attn_mfma8_bwd_dkv(const float* qkv, const float* d_o, const float* lse, const float* delta, float* dqkv, int B, int heads, int L,
+                        float sc, hipStream_t s);
 }
 static int g_attn_mfma_bwd_all = 1;   // (afd_debug_attn_rows(10) off / (11) on): the MFMA d = 8 backward also at L = 1024 -- with the K / V tiles
                                       // prefetched through registers it beats the all-VALU pair there too (1.31 vs 1.49 ms at B = 256)
@@ -357,7 +359,7 @@ int afd_attn_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d
   AFD_REQUIRE(B <= 65535 && heads <= 65535, "afd_attn_fwd: grid too large");
   hipStream_t s = as_stream(st);
   const float sc = 1.0f / sqrtf((float)d);
-  if (g_attn_rows == 0 && attn_mfma8_ok(d, L)) { attn_mfma8_fwd(qkv, o, lse, B, heads, L, sc, s); return check_launch("afd_attn_fwd"); }
+  if (g_attn_rows == 0 && attn_mfma8_ok(d, L)) { attn_mfma8_fwd(qkv, o, lse, B, heads, d, L, sc, s); return check_launch("afd_attn_fwd"); }
   // rows per lane by head dim (register budget): 4,4,4,2,2,1
   switch (d) {
     case 2:  launch_fwd<2, 4>(qkv, o, lse, B, heads, L, sc, s); break;
@@ -384,7 +386,9 @@ int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float
   hipStream_t s = as_stream(st);
   const float sc = 1.0f / sqrtf((float)d);
   if (g_attn_rows == 0 && attn_mfma8_ok(d, L) && (L < 1024 || g_attn_mfma_bwd_all)) {
-    attn_mfma8_bwd(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, L, sc, s);
+    attn_mfma8_bwd_dq(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, d, L, sc, s);
+    if (d == 8) attn_mfma8_bwd_dkv(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s);
+    else launch_dkv<16, 2>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s);       // (the d = 16 dK / dV pass stays on the vector kernel)
     return check_launch("afd_attn_bwd");
   }
   switch (d) {      // dQ pass: rows per lane 4,4,4,2,2,1

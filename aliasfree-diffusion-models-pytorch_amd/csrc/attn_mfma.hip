@@ -1,5 +1,6 @@
-// attn_mfma.hip -- attention core for head dim 8 (the 16x16 and 32x32 maps: 70 % of attention FLOPs) with
-// the two d-contractions of every pass on the fp32 matrix cores.
+// attn_mfma.hip -- attention core for head dim 8 and 16 (the 16x16 and 32x32 maps: sa1, sa5, sa6 -- 90 % of attention FLOPs)
+// with the two d-contractions of every pass on the matrix cores.  (Written for d = 8; templated on D in round 2: at d = 16
+// a lane half carries 8 of the 16 head dims, so a 32x32x16 MFMA holds ONE cross term and a tile takes six.)
 //
 // S^T = K Q^T (and dP^T = V dO^T) are matrix-core products over d = 8 -- at fp32 accuracy on the bf16 path (three
 // v_mfma_f32_32x32x16_bf16 per 32x32 tile on exact three-piece splits of the operands, see split3 below).  Their accumulator layout -- lane = query column (l & 31), the 16 registers = 16 of the 32 keys, the other 16 in
@@ -8,40 +9,34 @@
 // that both tiles of a wave share.  Compared with the all-VALU kernels this removes 8 of 21 (forward),
 // 16 of 30 (dQ) and 16 of 38 (dK/dV) vector instructions per (query, key) pair.
 // Scores live in the log2 domain: log2(e)/sqrt(d) is folded into the Q (K) fragments, exp is v_exp_f32.
-// Requirements: d == 8, L % 256 == 0 (others use attn.hip).  Deterministic, no atomics.
+// Requirements: d in {8, 16}, L % 256 == 0 (others use attn.hip).  Deterministic, no atomics.
 #include "common.h"
 
 namespace afd {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int kD = 8, kTK = 64;                      // head dim, rows of the streamed operand per LDS tile
-constexpr int kNE = kD * kTK / 256;                  // staged values per thread and operand
+constexpr int kTK = 64;                              // rows of the streamed operand per LDS tile
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, kWave); }     // value of lane ^ 32
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// stage a (8, L) j-major operand tile [r0, r0+64) into LDS both d-major [8][64] and row-major [64][8]
-__device__ __forceinline__ void stage_both(const float* __restrict__ src, int L, int r0, float* __restrict__ dmaj,
-                                           float* __restrict__ rmaj, float mul) {
-  for (int i = threadIdx.x; i < kD * kTK; i += 256) {
-    const int j = i / kTK, rr = i % kTK;
-    const float v = src[(long)j * L + r0 + rr] * mul;
-    dmaj[j * kTK + rr] = v;
-    if (rmaj) rmaj[rr * kD + j] = v;
-  }
-}
 // rank-8 updates run as packed f32 FMAs (v_pk_fma_f32, the scalar broadcast through op_sel): measured 5.4 cycles per
 // wave instruction against 4.3 for one v_fma_f32, i.e. 1.6x the FMA rate.  An LDS row of 8 is four register pairs.
 using f2 = __attribute__((ext_vector_type(2))) float;
-__device__ __forceinline__ void load_row8(const float* __restrict__ p, f2 (&v)[4]) {
-  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
-  v[0] = (f2){a.x, a.y}; v[1] = (f2){a.z, a.w}; v[2] = (f2){b.x, b.y}; v[3] = (f2){b.z, b.w};
+template <int D>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, f2 (&v)[D / 2]) {
+#pragma unroll
+  for (int q = 0; q < D / 4; ++q) {
+    const float4 a = reinterpret_cast<const float4*>(p)[q];
+    v[2 * q] = (f2){a.x, a.y}; v[2 * q + 1] = (f2){a.z, a.w};
+  }
 }
-__device__ __forceinline__ void axpy8(f2 (&acc)[4], float s, const f2 (&v)[4]) {
+template <int D>
+__device__ __forceinline__ void axpy(f2 (&acc)[D / 2], float s, const f2 (&v)[D / 2]) {
   const f2 ss = {s, s};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = __builtin_elementwise_fma(ss, v[i], acc[i]);
+  for (int i = 0; i < D / 2; ++i) acc[i] = __builtin_elementwise_fma(ss, v[i], acc[i]);
 }
 
 // ---- fp32-accurate d-contractions on the bf16 matrix path ----------------------------------------------------------
@@ -57,90 +52,120 @@ __device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c)
   b = (__bf16)r; const float r2 = r - (float)b;
   c = (__bf16)r2;
 }
-// B side (the row a lane keeps in registers for the whole kernel): halves (0 | 1) carry  M1: b1 | b1,  M2: b2 | b1,  M3: b2 | b3
-__device__ __forceinline__ void row_frags(const float (&x)[kD], int half, bf8 (&f)[3]) {
+// d = 16: a lane half carries head dims 8 half .. 8 half + 7, every fragment is one piece, six MFMAs per tile.
+// B side (the row a lane keeps in registers for the whole kernel): d = 8: halves (0 | 1) carry  M1: b1 | b1,  M2: b2 | b1,
+// M3: b2 | b3;  d = 16: f[m] = piece m of this half's eight dims.
+template <int D>
+__device__ __forceinline__ void row_frags(const float (&x)[D], int half, bf8 (&f)[3]) {
   bf8 p1, p2, p3;
 #pragma unroll
-  for (int d = 0; d < kD; ++d) { __bf16 a, b, c; split3(x[d], a, b, c); p1[d] = a; p2[d] = b; p3[d] = c; }
-  f[0] = p1; f[1] = half ? p1 : p2; f[2] = half ? p3 : p2;
+  for (int j = 0; j < 8; ++j) {
+    __bf16 a, b, c;
+    split3(D == 8 ? x[j] : (half ? x[(8 + j) % D] : x[j]), a, b, c);
+    p1[j] = a; p2[j] = b; p3[j] = c;
+  }
+  if (D == 8) { f[0] = p1; f[1] = half ? p1 : p2; f[2] = half ? p3 : p2; }
+  else { f[0] = p1; f[1] = p2; f[2] = p3; }
 }
-// A side (the streamed operand): pieces in LDS as [piece][row][8 bf16] (one ds_read_b128 per fragment);
-// halves carry  M1: a1 | a2,  M2: a1 | a3,  M3: a2 | a1.  A thread stages the d-pair (2 jp, 2 jp + 1) of row rr.
+// A side (the streamed operand): pieces in LDS as 16-byte records (one ds_read_b128 per fragment) -- d = 8: [piece][row],
+// halves carry  M1: a1 | a2,  M2: a1 | a3,  M3: a2 | a1;  d = 16: [piece][half][row].  A thread stages the d-pair
+// (2 jp, 2 jp + 1) of row rr.
+template <int D>
 __device__ __forceinline__ void stage_pieces(uint32_t* __restrict__ P, int rr, int jp, float v0, float v1) {
   __bf16 a0, b0, c0, a1, b1, c1;
   split3(v0, a0, b0, c0); split3(v1, a1, b1, c1);
-  P[(0 * kTK + rr) * 4 + jp] = __builtin_bit_cast(uint32_t, (bf2){a0, a1});
-  P[(1 * kTK + rr) * 4 + jp] = __builtin_bit_cast(uint32_t, (bf2){b0, b1});
-  P[(2 * kTK + rr) * 4 + jp] = __builtin_bit_cast(uint32_t, (bf2){c0, c1});
+  const int rec = D == 8 ? rr : (jp >> 2) * kTK + rr, w = jp & 3, ps = (D / 8) * kTK;       // records per piece
+  P[(0 * ps + rec) * 4 + w] = __builtin_bit_cast(uint32_t, (bf2){a0, a1});
+  P[(1 * ps + rec) * 4 + w] = __builtin_bit_cast(uint32_t, (bf2){b0, b1});
+  P[(2 * ps + rec) * 4 + w] = __builtin_bit_cast(uint32_t, (bf2){c0, c1});
 }
+template <int D>
 __device__ __forceinline__ void load_frags(const uint32_t* __restrict__ P, int row, int half, bf8 (&a)[3]) {
   const bf8* p = reinterpret_cast<const bf8*>(P);
-  a[0] = p[(half ? 1 : 0) * kTK + row]; a[1] = p[(half ? 2 : 0) * kTK + row]; a[2] = p[(half ? 0 : 1) * kTK + row];
+  if (D == 8) { a[0] = p[(half ? 1 : 0) * kTK + row]; a[1] = p[(half ? 2 : 0) * kTK + row]; a[2] = p[(half ? 0 : 1) * kTK + row]; }
+  else {
+#pragma unroll
+    for (int m = 0; m < 3; ++m) a[m] = p[(m * 2 + half) * kTK + row];
+  }
 }
-__device__ __forceinline__ f32x16 dot8x3(const bf8 (&a)[3], const bf8 (&b)[3]) {
+template <int D>
+__device__ __forceinline__ f32x16 dotx3(const bf8 (&a)[3], const bf8 (&b)[3]) {
   f32x16 c;
 #pragma unroll
   for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  if (D == 8) {
 #pragma unroll
-  for (int m = 0; m < 3; ++m) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[m], c, 0, 0, 0);
+    for (int m = 0; m < 3; ++m) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[m], c, 0, 0, 0);
+  } else {                                                            // the six leading cross terms, one per MFMA
+    constexpr int TA[6] = {0, 1, 0, 2, 1, 0}, TB[6] = {0, 0, 1, 0, 1, 2};
+#pragma unroll
+    for (int m = 0; m < 6; ++m) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[m]], b[TB[m]], c, 0, 0, 0);
+  }
   return c;
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward: workgroup = 256 queries (4 waves x 2 query tiles of 32), streams K/V in tiles of 64 keys
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd_mfma8(const float* __restrict__ qkv, float* __restrict__ o,
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const float* __restrict__ qkv, float* __restrict__ o,
                                                       float* __restrict__ lse, int heads, int L, float scale) {
-  __shared__ __attribute__((aligned(16))) uint32_t Kp[3 * kTK * 4];  // K pieces (MFMA A fragments)
-  __shared__ __attribute__((aligned(16))) float Vr[kTK * kD];       // V, row-major (P V rows)
-  const int b = blockIdx.z, h = blockIdx.y, C = heads * kD;
+  __shared__ __attribute__((aligned(16))) uint32_t Kp[3 * (D / 8) * kTK * 4];  // K pieces (MFMA A fragments)
+  __shared__ __attribute__((aligned(16))) float Vr[kTK * D];       // V, row-major (P V rows)
+  const int b = blockIdx.z, h = blockIdx.y, C = heads * D;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-  const float* qp = qkv + ((long)b * 3 * C + h * kD) * L;
+  const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
   const float* kp = qp + (long)C * L;
   const float* vp = kp + (long)C * L;
   const int q0 = blockIdx.x * 256 + wv * 64;                          // this wave's first query
   bf8 bq[2][3];                                                       // B fragments of the two query tiles
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    float x[kD];
+    float x[D];
 #pragma unroll
-    for (int d = 0; d < kD; ++d) x[d] = qp[(long)d * L + q0 + j * 32 + l31] * (scale * kLog2e);
-    row_frags(x, half, bq[j]);
+    for (int d = 0; d < D; ++d) x[d] = qp[(long)d * L + q0 + j * 32 + l31] * (scale * kLog2e);
+    row_frags<D>(x, half, bq[j]);
   }
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
-  f2 oa[2][4];
+  f2 oa[2][D / 2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) oa[j][i] = (f2){0.f, 0.f};
+    for (int i = 0; i < D / 2; ++i) oa[j][i] = (f2){0.f, 0.f};
 
-  // the next K / V tile travels global -> registers while the current one is multiplied: a thread owns the d-pair
-  // (2 jp, 2 jp + 1) of row rr (kNE = 2 values per operand)
-  static_assert(kNE == 2, "staging assumes one d-pair per thread");
-  const int jp = threadIdx.x >> 6, rr = threadIdx.x & 63;
-  float kreg[kNE], vreg[kNE];
+  // the next K / V tile travels global -> registers while the current one is multiplied: a thread owns the d-pairs
+  // (2 jp, 2 jp + 1), jp = (tid >> 6) + 4 e, of row rr
+  constexpr int NP = D / 8;
+  const int jp0 = threadIdx.x >> 6, rr = threadIdx.x & 63;
+  float kreg[NP][2], vreg[NP][2];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int e = 0; e < kNE; ++e) {
-      kreg[e] = kp[(long)(2 * jp + e) * L + k0 + rr];
-      vreg[e] = vp[(long)(2 * jp + e) * L + k0 + rr];
-    }
+    for (int e = 0; e < NP; ++e)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        kreg[e][h] = kp[(long)(2 * (jp0 + 4 * e) + h) * L + k0 + rr];
+        vreg[e][h] = vp[(long)(2 * (jp0 + 4 * e) + h) * L + k0 + rr];
+      }
   };
   fetch(0);
   for (int k0 = 0; k0 < L; k0 += kTK) {
     __syncthreads();
-    stage_pieces(Kp, rr, jp, kreg[0], kreg[1]);
-    *reinterpret_cast<float2*>(Vr + rr * kD + 2 * jp) = make_float2(vreg[0], vreg[1]);
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const int jp = jp0 + 4 * e;
+      stage_pieces<D>(Kp, rr, jp, kreg[e][0], kreg[e][1]);
+      *reinterpret_cast<float2*>(Vr + rr * D + 2 * jp) = make_float2(vreg[e][0], vreg[e][1]);
+    }
     __syncthreads();
     if (k0 + kTK < L) fetch(k0 + kTK);
 #pragma unroll
     for (int kt = 0; kt < kTK / 32; ++kt) {
       bf8 ak[3];
-      load_frags(Kp, kt * 32 + l31, half, ak);
+      load_frags<D>(Kp, kt * 32 + l31, half, ak);
       f32x16 sc[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        sc[j] = dot8x3(ak, bq[j]);
+        sc[j] = dotx3<D>(ak, bq[j]);
         float mx = sc[j][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[j][r]);
@@ -149,18 +174,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma8(const float* __restrict
         const float alpha = __builtin_amdgcn_exp2f(m[j] - mn);        // m = -inf first: exp2(-inf) = 0
         l[j] *= alpha;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) oa[j][i] *= alpha;
+        for (int i = 0; i < D / 2; ++i) oa[j][i] *= alpha;
         m[j] = mn;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        f2 v[4];
-        load_row8(Vr + (kt * 32 + acc_row(r, half)) * kD, v);         // shared by both query tiles
+        f2 v[D / 2];
+        load_row<D>(Vr + (kt * 32 + acc_row(r, half)) * D, v);         // shared by both query tiles
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float p = __builtin_amdgcn_exp2f(sc[j][r] - m[j]);
           l[j] += p;
-          axpy8(oa[j], p, v);
+          axpy<D>(oa[j], p, v);
         }
       }
     }
@@ -171,211 +196,229 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma8(const float* __restrict
     const float inv = 1.0f / lt;
     const int qi = q0 + j * 32 + l31;
 #pragma unroll
-    for (int d = 0; d < kD; ++d) {
+    for (int d = 0; d < D; ++d) {
       const float mine = oa[j][d >> 1][d & 1];
       const float t = mine + xhalf(mine);
-      if (half == 0) o[((long)b * C + h * kD + d) * L + qi] = t * inv;
+      if (half == 0) o[((long)b * C + h * D + d) * L + qi] = t * inv;
     }
     if (half == 0) lse[((long)b * heads + h) * L + qi] = (m[j] + __builtin_amdgcn_logf(lt)) * kLn2;   // v_log_f32 = log2
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// dQ (and delta = rowsum(dO * O)): same tiling as forward; S^T and dP^T on MFMA
+// dQ (and delta = rowsum(dO * O)): tiling of the forward with TJ query tiles per wave (d = 16: one -- 246 VGPRs at d = 8
+// leave no room for 16-wide rows of a second tile); S^T and dP^T on MFMA
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma8(const float* __restrict__ qkv, const float* __restrict__ o,
+template <int D, int TJ>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const float* __restrict__ qkv, const float* __restrict__ o,
                                                          const float* __restrict__ d_o, const float* __restrict__ lse,
                                                          float* __restrict__ dqkv, float* __restrict__ delta_out,
                                                          int heads, int L, float scale) {
-  __shared__ __attribute__((aligned(16))) uint32_t Kp[3 * kTK * 4];  // K pieces (A fragments of S^T)
-  __shared__ __attribute__((aligned(16))) uint32_t Vp[3 * kTK * 4];  // V pieces (A fragments of dP^T)
-  __shared__ __attribute__((aligned(16))) float Kr[kTK * kD];
-  const int b = blockIdx.z, h = blockIdx.y, C = heads * kD;
+  __shared__ __attribute__((aligned(16))) uint32_t Kp[3 * (D / 8) * kTK * 4];  // K pieces (A fragments of S^T)
+  __shared__ __attribute__((aligned(16))) uint32_t Vp[3 * (D / 8) * kTK * 4];  // V pieces (A fragments of dP^T)
+  __shared__ __attribute__((aligned(16))) float Kr[kTK * D];
+  const int b = blockIdx.z, h = blockIdx.y, C = heads * D;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-  const float* qp = qkv + ((long)b * 3 * C + h * kD) * L;
+  const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
   const float* kp = qp + (long)C * L;
   const float* vp = kp + (long)C * L;
-  const long ob = ((long)b * C + h * kD) * L;
-  const int q0 = blockIdx.x * 256 + wv * 64;
-  bf8 bq[2][3], bg[2][3];
-  float lsq[2], dlt[2];
-  f2 dq[2][4];
+  const long ob = ((long)b * C + h * D) * L;
+  const int q0 = blockIdx.x * (128 * TJ) + wv * (32 * TJ);
+  bf8 bq[TJ][3], bg[TJ][3];
+  float lsq[TJ], dlt[TJ];
+  f2 dq[TJ][D / 2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < TJ; ++j) {
     const int qi = q0 + j * 32 + l31;
-    float dpart = 0.f, xq[kD], xg[kD];
+    float dpart = 0.f, xq[D], xg[D];
 #pragma unroll
-    for (int d = 0; d < kD; ++d) {
+    for (int d = 0; d < D; ++d) {
       xq[d] = qp[(long)d * L + qi] * (scale * kLog2e);
       xg[d] = d_o[ob + (long)d * L + qi];
       dpart = fmaf(xg[d], o[ob + (long)d * L + qi], dpart);
     }
-    row_frags(xq, half, bq[j]);
-    row_frags(xg, half, bg[j]);
+    row_frags<D>(xq, half, bq[j]);
+    row_frags<D>(xg, half, bg[j]);
     dlt[j] = dpart;
     lsq[j] = lse[((long)b * heads + h) * L + qi] * kLog2e;
     if (half == 0) delta_out[((long)b * heads + h) * L + qi] = dlt[j];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dq[j][i] = (f2){0.f, 0.f};
+    for (int i = 0; i < D / 2; ++i) dq[j][i] = (f2){0.f, 0.f};
   }
-  const int jp = threadIdx.x >> 6, rr = threadIdx.x & 63;      // staging: d-pair (2 jp, 2 jp + 1) of row rr
-  float kreg[kNE], vreg[kNE];                           // next K / V tile in flight during the multiplies
+  constexpr int NP = D / 8;                             // staging: d-pairs (2 jp, 2 jp + 1), jp = (tid >> 6) + 4 e, of row rr
+  const int jp0 = threadIdx.x >> 6, rr = threadIdx.x & 63;
+  float kreg[NP][2], vreg[NP][2];                       // next K / V tile in flight during the multiplies
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int e = 0; e < kNE; ++e) {
-      kreg[e] = kp[(long)(2 * jp + e) * L + k0 + rr];
-      vreg[e] = vp[(long)(2 * jp + e) * L + k0 + rr];
-    }
+    for (int e = 0; e < NP; ++e)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        kreg[e][h] = kp[(long)(2 * (jp0 + 4 * e) + h) * L + k0 + rr];
+        vreg[e][h] = vp[(long)(2 * (jp0 + 4 * e) + h) * L + k0 + rr];
+      }
   };
   fetch(0);
   for (int k0 = 0; k0 < L; k0 += kTK) {
     __syncthreads();
-    stage_pieces(Kp, rr, jp, kreg[0], kreg[1]);
-    stage_pieces(Vp, rr, jp, vreg[0], vreg[1]);
-    *reinterpret_cast<float2*>(Kr + rr * kD + 2 * jp) = make_float2(kreg[0], kreg[1]);
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const int jp = jp0 + 4 * e;
+      stage_pieces<D>(Kp, rr, jp, kreg[e][0], kreg[e][1]);
+      stage_pieces<D>(Vp, rr, jp, vreg[e][0], vreg[e][1]);
+      *reinterpret_cast<float2*>(Kr + rr * D + 2 * jp) = make_float2(kreg[e][0], kreg[e][1]);
+    }
     __syncthreads();
     if (k0 + kTK < L) fetch(k0 + kTK);
 #pragma unroll
     for (int kt = 0; kt < kTK / 32; ++kt) {
       bf8 ak[3], av[3];
-      load_frags(Kp, kt * 32 + l31, half, ak);
-      load_frags(Vp, kt * 32 + l31, half, av);
-      f32x16 sc[2], dp[2];
+      load_frags<D>(Kp, kt * 32 + l31, half, ak);
+      load_frags<D>(Vp, kt * 32 + l31, half, av);
+      f32x16 sc[TJ], dp[TJ];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        sc[j] = dot8x3(ak, bq[j]);
-        dp[j] = dot8x3(av, bg[j]);
+      for (int j = 0; j < TJ; ++j) {
+        sc[j] = dotx3<D>(ak, bq[j]);
+        dp[j] = dotx3<D>(av, bg[j]);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        f2 kr[4];
-        load_row8(Kr + (kt * 32 + acc_row(r, half)) * kD, kr);
+        f2 kr[D / 2];
+        load_row<D>(Kr + (kt * 32 + acc_row(r, half)) * D, kr);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TJ; ++j) {
           const float ds = __builtin_amdgcn_exp2f(sc[j][r] - lsq[j]) * (dp[j][r] - dlt[j]);
-          axpy8(dq[j], ds, kr);
+          axpy<D>(dq[j], ds, kr);
         }
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < TJ; ++j) {
     const int qi = q0 + j * 32 + l31;
 #pragma unroll
-    for (int d = 0; d < kD; ++d) {
+    for (int d = 0; d < D; ++d) {
       const float mine = dq[j][d >> 1][d & 1];
       const float t = mine + xhalf(mine);
-      if (half == 0) dqkv[((long)b * 3 * C + h * kD + d) * L + qi] = t * scale;
+      if (half == 0) dqkv[((long)b * 3 * C + h * D + d) * L + qi] = t * scale;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// dK, dV: workgroup = 256 keys (4 waves x 2 key tiles), streams Q / dO / lse / delta in tiles of 64 queries.
-// Tiles are [query rows x key columns]: lane = key, registers = 16 of 32 queries.
+// dK, dV: workgroup = 4 waves x TJ key tiles of 32 (d = 8: TJ = 2, 256 keys; d = 16: TJ = 1, 128 keys -- the resident
+// fragments, the dK / dV sums and the score tiles of a second tile do not fit beside 16-wide rows), streams Q / dO / lse /
+// delta in tiles of 64 queries.  Tiles are [query rows x key columns]: lane = key, registers = 16 of 32 queries.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma8(const float* __restrict__ qkv, const float* __restrict__ d_o,
+template <int D, int TJ>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           float* __restrict__ dqkv, int heads, int L, float scale) {
-  __shared__ __attribute__((aligned(16))) uint32_t Qp[3 * kTK * 4];  // Q pieces  (A fragments of S)
-  __shared__ __attribute__((aligned(16))) uint32_t Gp[3 * kTK * 4];  // dO pieces (A fragments of dP)
-  __shared__ __attribute__((aligned(16))) float Qr[kTK * kD];       // rows for dK += dS^T Q
-  __shared__ __attribute__((aligned(16))) float Gr[kTK * kD];       // rows for dV += P^T dO
+  __shared__ __attribute__((aligned(16))) uint32_t Qp[3 * (D / 8) * kTK * 4];  // Q pieces  (A fragments of S)
+  __shared__ __attribute__((aligned(16))) uint32_t Gp[3 * (D / 8) * kTK * 4];  // dO pieces (A fragments of dP)
+  __shared__ __attribute__((aligned(16))) float Qr[kTK * D];       // rows for dK += dS^T Q
+  __shared__ __attribute__((aligned(16))) float Gr[kTK * D];       // rows for dV += P^T dO
   __shared__ float Ls[kTK];
   __shared__ float Ds[kTK];
-  const int b = blockIdx.z, h = blockIdx.y, C = heads * kD;
+  const int b = blockIdx.z, h = blockIdx.y, C = heads * D;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-  const float* qp = qkv + ((long)b * 3 * C + h * kD) * L;
+  const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
   const float* kp = qp + (long)C * L;
   const float* vp = kp + (long)C * L;
-  const float* gp = d_o + ((long)b * C + h * kD) * L;
+  const float* gp = d_o + ((long)b * C + h * D) * L;
   const float* lp = lse + ((long)b * heads + h) * L;
   const float* dlp = delta + ((long)b * heads + h) * L;
-  const int key0 = blockIdx.x * 256 + wv * 64;
-  // B fragments of the wave's two key tiles (K scaled, V): a wave-private LDS image, one ds_read_b128 per fragment and
+  const int key0 = blockIdx.x * (128 * TJ) + wv * (32 * TJ);
+  // B fragments of the wave's key tiles (K scaled, V): a wave-private LDS image, one ds_read_b128 per fragment and
   // lane (in registers they cost 48 VGPRs, and the kernel must keep 2 waves / SIMD)
-  __shared__ bf8 Bf[4][2][2][3][64];
-  f2 dk[2][4], dv[2][4];
+  __shared__ bf8 Bf[4][TJ][2][3][64];
+  f2 dk[TJ][D / 2], dv[TJ][D / 2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    float xk[kD], xv[kD];
+  for (int j = 0; j < TJ; ++j) {
+    float xk[D], xv[D];
 #pragma unroll
-    for (int d = 0; d < kD; ++d) {
+    for (int d = 0; d < D; ++d) {
       xk[d] = kp[(long)d * L + key0 + j * 32 + l31] * (scale * kLog2e);
       xv[d] = vp[(long)d * L + key0 + j * 32 + l31];
     }
     bf8 t[3];
-    row_frags(xk, half, t);
+    row_frags<D>(xk, half, t);
 #pragma unroll
     for (int m = 0; m < 3; ++m) Bf[wv][j][0][m][lane] = t[m];
-    row_frags(xv, half, t);
+    row_frags<D>(xv, half, t);
 #pragma unroll
     for (int m = 0; m < 3; ++m) Bf[wv][j][1][m][lane] = t[m];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { dk[j][i] = (f2){0.f, 0.f}; dv[j][i] = (f2){0.f, 0.f}; }
+    for (int i = 0; i < D / 2; ++i) { dk[j][i] = (f2){0.f, 0.f}; dv[j][i] = (f2){0.f, 0.f}; }
   }
-  float qreg[kNE], greg[kNE], lreg = 0.f, dreg = 0.f;       // next Q / dO / lse / delta tile in flight during the multiplies
-  const int jp = threadIdx.x >> 6, rr = threadIdx.x & 63;      // staging: d-pair (2 jp, 2 jp + 1) of row rr
+  constexpr int NP = D / 8;                                 // staging: d-pairs (2 jp, 2 jp + 1), jp = (tid >> 6) + 4 e, of row rr
+  const int jp0 = threadIdx.x >> 6, rr = threadIdx.x & 63;
+  float qreg[NP][2], greg[NP][2], lreg = 0.f, dreg = 0.f;   // next Q / dO / lse / delta tile in flight during the multiplies
   auto fetch = [&](int t0) {
 #pragma unroll
-    for (int e = 0; e < kNE; ++e) {
-      qreg[e] = qp[(long)(2 * jp + e) * L + t0 + rr];
-      greg[e] = gp[(long)(2 * jp + e) * L + t0 + rr];
-    }
+    for (int e = 0; e < NP; ++e)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        qreg[e][hh] = qp[(long)(2 * (jp0 + 4 * e) + hh) * L + t0 + rr];
+        greg[e][hh] = gp[(long)(2 * (jp0 + 4 * e) + hh) * L + t0 + rr];
+      }
     if (threadIdx.x < kTK) { lreg = lp[t0 + threadIdx.x] * kLog2e; dreg = dlp[t0 + threadIdx.x]; }
   };
   fetch(0);
   for (int t0 = 0; t0 < L; t0 += kTK) {
     __syncthreads();
-    stage_pieces(Qp, rr, jp, qreg[0], qreg[1]);
-    stage_pieces(Gp, rr, jp, greg[0], greg[1]);
-    *reinterpret_cast<float2*>(Qr + rr * kD + 2 * jp) = make_float2(qreg[0], qreg[1]);
-    *reinterpret_cast<float2*>(Gr + rr * kD + 2 * jp) = make_float2(greg[0], greg[1]);
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const int jp = jp0 + 4 * e;
+      stage_pieces<D>(Qp, rr, jp, qreg[e][0], qreg[e][1]);
+      stage_pieces<D>(Gp, rr, jp, greg[e][0], greg[e][1]);
+      *reinterpret_cast<float2*>(Qr + rr * D + 2 * jp) = make_float2(qreg[e][0], qreg[e][1]);
+      *reinterpret_cast<float2*>(Gr + rr * D + 2 * jp) = make_float2(greg[e][0], greg[e][1]);
+    }
     if (threadIdx.x < kTK) { Ls[threadIdx.x] = lreg; Ds[threadIdx.x] = dreg; }
     __syncthreads();
     if (t0 + kTK < L) fetch(t0 + kTK);
 #pragma unroll
     for (int qt = 0; qt < kTK / 32; ++qt) {
       bf8 aq[3], ag[3];
-      load_frags(Qp, qt * 32 + l31, half, aq);
-      load_frags(Gp, qt * 32 + l31, half, ag);
-      f32x16 sc[2], dp[2];
+      load_frags<D>(Qp, qt * 32 + l31, half, aq);
+      load_frags<D>(Gp, qt * 32 + l31, half, ag);
+      f32x16 sc[TJ], dp[TJ];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < TJ; ++j) {
         bf8 bkj[3], bvj[3];
 #pragma unroll
         for (int m = 0; m < 3; ++m) { bkj[m] = Bf[wv][j][0][m][lane]; bvj[m] = Bf[wv][j][1][m][lane]; }
-        sc[j] = dot8x3(aq, bkj);
-        dp[j] = dot8x3(ag, bvj);
+        sc[j] = dotx3<D>(aq, bkj);
+        dp[j] = dotx3<D>(ag, bvj);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qr = qt * 32 + acc_row(r, half);
-        f2 qrow[4], grow[4];
-        load_row8(Qr + qr * kD, qrow);
-        load_row8(Gr + qr * kD, grow);
+        f2 qrow[D / 2], grow[D / 2];
+        load_row<D>(Qr + qr * D, qrow);
+        load_row<D>(Gr + qr * D, grow);
         const float ls = Ls[qr], dl = Ds[qr];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TJ; ++j) {
           const float p = __builtin_amdgcn_exp2f(sc[j][r] - ls);
           const float ds = p * (dp[j][r] - dl);
-          axpy8(dv[j], p, grow);
-          axpy8(dk[j], ds, qrow);
+          axpy<D>(dv[j], p, grow);
+          axpy<D>(dk[j], ds, qrow);
         }
         if ((r & 1) == 1) asm volatile("" ::: "memory");      // bound how many LDS rows are in flight (register budget)
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < TJ; ++j) {
     const int ki = key0 + j * 32 + l31;
 #pragma unroll
-    for (int d = 0; d < kD; ++d) {
+    for (int d = 0; d < D; ++d) {
       const float mk = dk[j][d >> 1][d & 1], mv = dv[j][d >> 1][d & 1];
       const float tk = mk + xhalf(mk), tv = mv + xhalf(mv);
       if (half == 0) {
-        dqkv[((long)b * 3 * C + C + h * kD + d) * L + ki] = tk * scale;
-        dqkv[((long)b * 3 * C + 2 * C + h * kD + d) * L + ki] = tv;
+        dqkv[((long)b * 3 * C + C + h * D + d) * L + ki] = tk * scale;
+        dqkv[((long)b * 3 * C + 2 * C + h * D + d) * L + ki] = tv;
       }
     }
   }
@@ -387,14 +430,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma8(const float* __rest
 // DESIGN.md section 6.
 
 // host-side launchers used by attn.hip
-bool attn_mfma8_ok(int d, int L) { return d == 8 && L % 256 == 0; }
-void attn_mfma8_fwd(const float* qkv, float* o, float* lse, int B, int heads, int L, float sc, hipStream_t s) {
-  hipLaunchKernelGGL(attn_fwd_mfma8, dim3(L / 256, heads, B), dim3(256), 0, s, qkv, o, lse, heads, L, sc);
+bool attn_mfma8_ok(int d, int L) { return (d == 8 || d == 16) && L % 256 == 0; }
+void attn_mfma8_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d, int L, float sc, hipStream_t s) {
+  if (d == 8) hipLaunchKernelGGL(attn_fwd_mfma<8>, dim3(L / 256, heads, B), dim3(256), 0, s, qkv, o, lse, heads, L, sc);
+  else hipLaunchKernelGGL(attn_fwd_mfma<16>, dim3(L / 256, heads, B), dim3(256), 0, s, qkv, o, lse, heads, L, sc);
 }
-void attn_mfma8_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta,
-                    int B, int heads, int L, float sc, hipStream_t s) {
-  hipLaunchKernelGGL(attn_bwd_dq_mfma8, dim3(L / 256, heads, B), dim3(256), 0, s, qkv, o, d_o, lse, dqkv, delta, heads, L, sc);
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma8, dim3(L / 256, heads, B), dim3(256), 0, s, qkv, d_o, lse, delta, dqkv, heads, L, sc);
+// dQ pass (+ delta) for d in {8, 16}; the dK / dV pass on these kernels only at d = 8: at d = 16 one key tile per wave is all
+// the registers hold, every 16-wide Q / dO row read from LDS then serves one tile instead of two and the pass is LDS-bound
+// (measured at sa1's shape: 138 us against 120 for the all-vector kernel with two key rows per lane, which stays)
+void attn_mfma8_bwd_dq(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta,
+                       int B, int heads, int d, int L, float sc, hipStream_t s) {
+  if (d == 8) hipLaunchKernelGGL((attn_bwd_dq_mfma<8, 2>), dim3(L / 256, heads, B), dim3(256), 0, s, qkv, o, d_o, lse, dqkv, delta, heads, L, sc);
+  else hipLaunchKernelGGL((attn_bwd_dq_mfma<16, 1>), dim3(L / 128, heads, B), dim3(256), 0, s, qkv, o, d_o, lse, dqkv, delta, heads, L, sc);
+}
+void attn_mfma8_bwd_dkv(const float* qkv, const float* d_o, const float* lse, const float* delta, float* dqkv, int B, int heads, int L,
+                        float sc, hipStream_t s) {
+  hipLaunchKernelGGL((attn_bwd_dkv_mfma<8, 2>), dim3(L / 256, heads, B), dim3(256), 0, s, qkv, d_o, lse, delta, dqkv, heads, L, sc);
 }
 
 }  // namespace afd
