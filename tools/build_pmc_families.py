@@ -47,8 +47,8 @@ for fam in ("fwd", "dgrad", "wgrad"):
     d["source"] = f"profiles/pmc_families.json: {src}, over tools/conv_family.py {fam} (one step's launches of the family, B=256)"
     out["conv3x3_" + fam] = d
 whole = [load(os.path.join(root, "pmc", k))[0] for k in ("fetch", "write", "sq")]
-groups = {"attn_bwd": {"attn_bwd_dq_k", "attn_bwd_dkv_k", "attn_bwd_dq_mfma8", "attn_bwd_dkv_mfma8", "attn_bwd_fused8"},
-          "attn_fwd": {"attn_fwd_k", "attn_fwd_mfma8"},
+groups = {"attn_bwd": {"attn_bwd_dq_k", "attn_bwd_dkv_k", "attn_bwd_dq_mfma", "attn_bwd_dkv_mfma"},
+          "attn_fwd": {"attn_fwd_k", "attn_fwd_mfma"},
           "filt_act_fwd_n3": {"filt_act_fwd_n3"}, "filt_act_bwd_n3": {"filt_act_bwd_n3"},
           "groupnorm1_stats": {"gn_fwd_reg", "gn_fwd_loop"}, "groupnorm1_bwd_apply": {"gn_bwd_apply"},
           "tok_head_fwd": {"tok_head_fwd", "tok_head_fwd_wide"}, "tok_tail_fwd": {"tok_tail_fwd", "tok_tail_fwd_wide"},
