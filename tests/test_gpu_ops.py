@@ -2,6 +2,7 @@
 torch-CPU autograd for the backward) and against the golden vectors produced by the reference.
 Tolerances are relative L2 in fp32; integer / schedule / quantisation results are bit-exact."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -401,6 +402,16 @@ def test_conv_weight_image_follows_the_batch_size(A):
             check("F5 conv bwd vs fp64", gx.cpu(), go, TOL, ("image per batch size", B, "dx"))
     finally:
         L.afd_debug_conv_path(64)
+
+
+def test_new_kernels_agree_with_fp32_kernels_at_odd_batches(A):
+    """tools/cross_check.py: 200 comparisons of the bf16x3 / streaming kernels against the fp32 Winograd / direct kernels at odd
+    batch sizes (33, 100, 129, 257: ragged last tiles on every map size), forward / dgrad / wgrad and the 1x1 gradients."""
+    import runpy
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with pytest.raises(SystemExit) as e:
+        runpy.run_path(os.path.join(root, "tools", "cross_check.py"), run_name="__main__")
+    assert e.value.code == 0
 
 
 def test_pointwise_full_batch_matches_double_precision(A):
