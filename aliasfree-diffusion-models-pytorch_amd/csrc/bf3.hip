@@ -174,13 +174,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf3(const float* __restrict__ x, 
         if (BF3_ABL & 1) {
           asm volatile("" :: "v"(a[0][0]), "v"(a[0][1]), "v"(a[0][2]), "v"(a[1][0]), "v"(bc[0]), "v"(bc[1]), "v"(bc[2]));
         } else {
-          // term-major: consecutive MFMAs go to different accumulators (a dependent pair would wait out the pipeline depth)
-          constexpr int TA[6] = {0, 1, 0, 2, 1, 0}, TB[6] = {0, 0, 1, 0, 1, 2};
+          // (term-major order -- consecutive MFMAs into different accumulators -- measured no faster and costs the 4-block
+          // form 12 spilled registers: back-to-back accumulation into one register block is free on this pipe)
 #pragma unroll
-          for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int ns = 0; ns < 2; ++ns)
-              acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][TA[t]], bc[TB[t]], acc[ns][ps], 0, 0, 0);
+          for (int ns = 0; ns < 2; ++ns) {
+            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][0], bc[0], acc[ns][ps], 0, 0, 0);
+            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][1], bc[0], acc[ns][ps], 0, 0, 0);
+            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][0], bc[1], acc[ns][ps], 0, 0, 0);
+            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][2], bc[0], acc[ns][ps], 0, 0, 0);
+            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][1], bc[1], acc[ns][ps], 0, 0, 0);
+            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ns][0], bc[2], acc[ns][ps], 0, 0, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!(BF3_ABL & 8)) { bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2]; }
@@ -228,6 +232,8 @@ static int bf3_nblk(long tiles, int N, int S) {
 // does the bf16x3 direct kernel take the layer (reduction width K, N output channels)?
 bool bf3_ok(int B, int K, int N, int H, int W) {
   if (g_bf3_mode == 1) return false;
+  // (4 x 4 maps: the same kernel with 8 images per tile was measured -- 32 tiles x N / 32 = 128-256 workgroups of one wave per
+  // SIMD: 20 / 41 us for 128->128 / 256->256 against the split-K Winograd kernel's 11 / 28 -- and is not instantiated)
   if (H != W || (W != 8 && W != 16 && W != 32)) return false;
   if (K % 32 || N % 32 || K < 32) return false;
   if ((long)B * K * H * W >= (1L << 31) || (long)B * N * H * W >= (1L << 31)) return false;
