@@ -149,7 +149,13 @@ def _emb_layer(emb_dim, out_channels):
 
 
 class _Stage(nn.Module):
+    _emb_pre = None       # (t, emb) set by UNet.forward for ONE call: this stage's time embedding of THAT t, computed with the
+    #                       other stages' in one launch
+
     def _emb(self, t):
+        pre, self._emb_pre = self._emb_pre, None
+        if pre is not None and pre[0] is t:
+            return pre[1]
         lin = self.emb_layer[1]
         return ops.SiluLinear.apply(t, lin.weight, lin.bias)
 

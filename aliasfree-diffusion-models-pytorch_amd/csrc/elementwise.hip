@@ -166,6 +166,28 @@ __global__ void silu_linear_fwd_k(const float* __restrict__ temb, const float* _
   s = wave_sum(s);
   if (lane == 0) out[wv] = s + (bias ? bias[n] : 0.f);
 }
+// the same for up to 8 layers that share temb (the six stages' emb_layer of one UNet forward: their input exists as soon as
+// the forward starts, so ONE launch replaces six small dependent ones); a wave finds its layer by the output offsets
+struct SiluBatch {
+  const float* w[8]; const float* bias[8]; float* out[8];
+  int N[8], first[9];            // outputs per row; first output column of layer i in the concatenated row
+  int n;
+};
+__global__ void silu_linear_fwd_batched_k(const float* __restrict__ temb, SiluBatch d, int B, int K) {
+  const long wv = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63, NT = d.first[d.n];
+  if (wv >= (long)B * NT) return;
+  const int b = wv / NT, col = wv % NT;
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < 8; ++j) if (j < d.n && col >= d.first[j]) i = j;
+  const int n = col - d.first[i];
+  const float* __restrict__ w = d.w[i];
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += silu(temb[(long)b * K + k]) * w[(long)n * K + k];
+  s = wave_sum(s);
+  if (lane == 0) d.out[i][(long)b * d.N[i] + n] = s + (d.bias[i] ? d.bias[i][n] : 0.f);
+}
 // dw[n,k] = sum_b dout[b,n] silu(temb[b,k]).  Block = one output row n x 32 columns k x 8 batch groups;
 // the 8 partial sums meet in LDS (fixed order).
 __global__ __launch_bounds__(256) void silu_linear_dw_k(const float* __restrict__ temb, const float* __restrict__ dout, float* __restrict__ dw,
@@ -357,6 +379,19 @@ int afd_silu_linear_fwd(const float* temb, const float* w, const float* bias, fl
   const long waves = (long)B * N;
   hipLaunchKernelGGL(silu_linear_fwd_k, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(st), temb, w, bias, out, B, K, N);
   return check_launch("afd_silu_linear_fwd");
+}
+int afd_silu_linear_fwd_batched(const float* temb, const afd_silu_desc* descs, int n, int B, int K, afd_stream_t st) {
+  AFD_REQUIRE(temb && descs && n > 0 && n <= 8 && B > 0 && K > 0, "afd_silu_linear_fwd_batched: bad argument (1..8 layers)");
+  SiluBatch d{};
+  d.n = n; d.first[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    AFD_REQUIRE(descs[i].w && descs[i].out && descs[i].N > 0, "afd_silu_linear_fwd_batched: bad descriptor %d", i);
+    d.w[i] = descs[i].w; d.bias[i] = descs[i].bias; d.out[i] = descs[i].out; d.N[i] = descs[i].N;
+    d.first[i + 1] = d.first[i] + descs[i].N;
+  }
+  const long waves = (long)B * d.first[n];
+  hipLaunchKernelGGL(silu_linear_fwd_batched_k, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(st), temb, d, B, K);
+  return check_launch("afd_silu_linear_fwd_batched");
 }
 int afd_silu_linear_bwd(const float* temb, const float* w, const float* dout, float* dw, float* dbias, float* dtemb,
                         int B, int K, int N, int accumulate, afd_stream_t st) {

@@ -933,6 +933,56 @@ class SiluLinear(_Fn):
         return dtemb, dw, db
 
 
+class SiluLinearBatched(_Fn):
+    """The emb_layer of several stages (each nn.Sequential(nn.SiLU(), nn.Linear(emb_dim, C_i)), ddpm_utils.py:208-214) on the SAME
+    time embedding in one launch: forward(temb, w_0, b_0, w_1, b_1, ...) -> (out_0, out_1, ...).  The input exists as soon as
+    the UNet forward starts, so one launch replaces six small dependent ones; the parameter gradients go the way
+    SiluLinear's do.  temb must not need a gradient (the conditional model keeps the per-stage op)."""
+
+    @staticmethod
+    def forward(ctx, temb, *wb):
+        import ctypes, struct
+        ws, bs = wb[0::2], wb[1::2]
+        _chk(temb, *ws, *bs)
+        temb = _c(temb)
+        B, K = temb.shape
+        outs = [torch.empty(B, w.shape[0], device=temb.device, dtype=torch.float32) for w in ws]
+        desc = b"".join(struct.pack("<QQQi4x", _p(w) or 0, _p(b) or 0, _p(o), w.shape[0]) for w, b, o in zip(ws, bs, outs))
+        buf = ctypes.create_string_buffer(desc, len(desc))
+        lib().afd_silu_linear_fwd_batched(_p(temb), ctypes.addressof(buf), len(ws), B, K, _stream())
+        ctx.save_for_backward(temb, *ws)
+        ctx.params = [(w if isinstance(w, torch.nn.Parameter) else None, b if isinstance(b, torch.nn.Parameter) else None)
+                      for w, b in zip(ws, bs)]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        temb, *ws = ctx.saved_tensors
+        B, K = temb.shape
+        grads = [None]
+        for w, dout, (wp, bp) in zip(ws, douts, ctx.params):
+            N = w.shape[0]
+            if dout is None:
+                grads += [None, None]
+                continue
+            dout = _c(dout)
+            if _direct(wp, bp):
+                if _GradMode.side is not None:                     # parameter gradients only: off the critical path
+                    pw, pb = _p(wp.grad), _p(bp.grad)
+                    defer_to_side_stream(lambda st, temb=temb, w=w, dout=dout, pw=pw, pb=pb, N=N: lib().afd_silu_linear_bwd(
+                        _p(temb), _p(w), _p(dout), pw, pb, None, B, K, N, 1, st), temb, w, dout, writes=(wp, bp))
+                else:
+                    lib().afd_silu_linear_bwd(_p(temb), _p(w), _p(dout), _p(wp.grad), _p(bp.grad), None, B, K, N, 1, _stream())
+                    _wrote(wp, bp)
+                grads += [None, None]
+                continue
+            dw = torch.empty_like(w)
+            db = torch.empty(N, device=w.device, dtype=torch.float32)
+            lib().afd_silu_linear_bwd(_p(temb), _p(w), _p(dout), _p(dw), _p(db), None, B, K, N, 0, _stream())
+            grads += [dw, db]
+        return tuple(grads)
+
+
 # ---------------------------------------------------------------------------------------------
 # F14 / F15 / F16
 # ---------------------------------------------------------------------------------------------

@@ -252,6 +252,15 @@ int afd_silu_linear_fwd(const float* temb, const float* w, const float* bias, fl
                         int B, int K, int N, afd_stream_t stream);
 int afd_silu_linear_bwd(const float* temb, const float* w, const float* dout, float* dw, float* dbias,
                         float* dtemb /* or NULL; accumulated into */, int B, int K, int N, int accumulate, afd_stream_t stream);
+/* the forward of up to 8 such layers that share temb in ONE launch (the six stages' emb_layer of a UNet forward: their
+ * input exists as soon as the forward starts).  descs: HOST array of n entries. */
+typedef struct afd_silu_desc {
+  const float* w;        /* (N, K) */
+  const float* bias;     /* (N) or NULL */
+  float* out;            /* (B, N) */
+  int N;
+} afd_silu_desc;
+int afd_silu_linear_fwd_batched(const float* temb, const afd_silu_desc* descs, int n, int B, int K, afd_stream_t stream);
 
 /* label conditioning: out[b, :] = temb[b, :] + table[y[b], :]   (nn.Embedding lookup + add, ddpm_models.py:254,276-277)
  * y: (B,) int64 class indices in [0, num_classes); out may alias temb.
