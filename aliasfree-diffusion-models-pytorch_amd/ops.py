@@ -7,6 +7,7 @@ contiguous, on a HIP device; anything else raises (there is no CPU / eager fallb
 import weakref
 
 import numpy as np
+import os
 import torch
 
 from ._lib import AfdError, lib
@@ -833,14 +834,15 @@ class UpCat(_Fn):
         bs = (Cs + C) * plane
         L = lib()
         dx = torch.empty(B, C, H, W, device=dout.device, dtype=torch.float32)
-        dskip = torch.empty(B, Cs, 2 * H, 2 * W, device=dout.device, dtype=torch.float32)
         up_ptr = dout.data_ptr() + 4 * Cs * plane
         if ctx.mode == "filt":
             L.afd_filt_up2_bwd(up_ptr, _p(dx), B, C, H, W, bs, 0, ctx.taps.ptr, ctx.taps.N, _stream())
         else:
             L.afd_bilinear_up2_bwd(up_ptr, _p(dx), B, C, H, W, bs, _stream())
-        L.afd_copy_batched(_p(dout), _p(dskip), B, Cs * plane, bs, 0, _stream())
-        return dx, dskip, None, None
+        # the skip's gradient is a channel slice of dout: returned as a VIEW.  Every skip tensor has a second consumer (the next
+        # encoder stage), so autograd adds the two gradients anyway -- its add reads the slice in place and writes a contiguous
+        # sum; the copy that used to materialise the slice first (3 launches, 2 tensor passes per step) is gone (8.54 -> 8.48 ms/step, same box).
+        return dx, dout[:, :Cs], None, None
 
 
 # ---------------------------------------------------------------------------------------------
