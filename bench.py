@@ -155,7 +155,8 @@ def kernel_table(dev, B):
         add("filt_down2_bwd", ev_time(lambda: L.afd_filt_down2_bwd(P(y), P(x), B, C, S, S, 0, 0, tk.ptr, 3, s)), bytes_=4 * (e_hi + e_lo), bound="hbm")
         add("filt_up2_fwd", ev_time(lambda: L.afd_filt_up2_fwd(P(y), P(x), B, C, S // 2, S // 2, 0, 0, tk.ptr, 3, s)), bytes_=4 * (e_hi + e_lo), bound="hbm")
         add("filt_up2_bwd", ev_time(lambda: L.afd_filt_up2_bwd(P(x), P(y), B, C, S // 2, S // 2, 0, 0, tk.ptr, 3, s)), bytes_=4 * (e_hi + e_lo), bound="hbm")
-        add("concat_copy", 2 * ev_time(lambda: L.afd_copy_batched(P(x), P(x), B, C * S * S, 0, 0, s)), bytes_=2 * 8 * e_hi, launches=2, bound="hbm")
+        # (forward only: the backward hands the skip's gradient on as a view of the concat gradient)
+        add("concat_copy", ev_time(lambda: L.afd_copy_batched(P(x), P(x), B, C * S * S, 0, 0, s)), bytes_=8 * e_hi, launches=1, bound="hbm")
         del x, y
     # ---- attention blocks (F10): core + the fused token-wise chains + their parameter gradients --------------------
     for (C, S) in ATTN:
