@@ -194,8 +194,8 @@ __device__ __forceinline__ float gelu_piece(float u, const float4* __restrict__ 
 }
 __device__ __forceinline__ float gelu_tab(float u, const float4* __restrict__ T) { return u * gelu_piece(u, T); }
 __device__ __forceinline__ float gelu_grad_tab(float u, const float4* __restrict__ T) { return gelu_piece(u, T + kGeluPieces); }
-__device__ __forceinline__ void load_gelu_table(float4* __restrict__ T, int first, int count) {   // 256-thread workgroups
-  for (int i = threadIdx.x; i < count; i += 256) T[i] = g_gelu_tab[first + i];
+__device__ __forceinline__ void load_gelu_table(float4* __restrict__ T, int first, int count) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) T[i] = g_gelu_tab[first + i];
   __syncthreads();
 }
 
@@ -299,11 +299,15 @@ __device__ __forceinline__ void act_lookup(float U, const float4* __restrict__ T
 __device__ __forceinline__ float act_cubic(const float4& c, float t) { return fmaf(fmaf(fmaf(c.w, t, c.z), t, c.y), t, c.x); }
 
 // F4 fast forward: y = down2(gelu(up2(v))), v = prologue(x).
-template <int S, bool FULL>
-__global__ __launch_bounds__(256) void filt_act_fwd_n3(const float* __restrict__ x, float* __restrict__ y,
+// STATS (small samples, C * S <= 1024): the workgroup IS one sample (blockDim = C * S threads, one lane per column of every
+// plane), so it computes the GroupNorm(1, C) statistics itself -- two-pass, from the columns it already holds in registers --
+// applies them and writes {mean, rstd} to stats_out for the backward kernels: no separate statistics launch.
+template <int S, bool FULL, bool STATS = false>
+__global__ __launch_bounds__(STATS ? 1024 : 256) void filt_act_fwd_n3(const float* __restrict__ x, float* __restrict__ y,
                                                        long planes, int C, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ res, Taps3 u, Taps3 d) {
+                                                       const float* __restrict__ res, Taps3 u, Taps3 d,
+                                                       float* __restrict__ stats_out = nullptr, float eps = 0.f) {
   __shared__ float4 T[kGeluPieces];
   load_gelu_table(T, 0, kGeluPieces);
   Lane<S> L(planes);
@@ -312,10 +316,30 @@ __global__ __launch_bounds__(256) void filt_act_fwd_n3(const float* __restrict__
   if (FULL && !L.live) return;            // a whole wave beyond the last plane (the grid is rounded up to 4 waves): wave-uniform
   const bool live = FULL || L.live;
   float sc, sh;
-  if (live) plane_affine(stats, gamma, beta, b, c, sc, sh); else { sc = 1.f; sh = 0.f; }
   float xv[S + 2];
+  if (STATS) {
+    __shared__ float red[16];
 #pragma unroll
-  for (int i = 0; i < S; ++i) xv[i] = live ? fmaf(x[base + i * S], sc, sh) : 0.f;
+    for (int i = 0; i < S; ++i) xv[i] = x[base + i * S];
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < S; ++i) sm += xv[i];
+    const float n = (float)C * S * S;
+    const float mean = block_sum(sm, red) / n;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < S; ++i) { const float dd = xv[i] - mean; m2 = fmaf(dd, dd, m2); }
+    const float rstd = 1.0f / sqrtf(block_sum(m2, red) / n + eps);
+    if (threadIdx.x == 0) { stats_out[2 * b] = mean; stats_out[2 * b + 1] = rstd; }
+    sc = rstd * (gamma ? gamma[c] : 1.f);
+    sh = (beta ? beta[c] : 0.f) - mean * sc;
+#pragma unroll
+    for (int i = 0; i < S; ++i) xv[i] = fmaf(xv[i], sc, sh);
+  } else {
+    if (live) plane_affine(stats, gamma, beta, b, c, sc, sh); else { sc = 1.f; sh = 0.f; }
+#pragma unroll
+    for (int i = 0; i < S; ++i) xv[i] = live ? fmaf(x[base + i * S], sc, sh) : 0.f;
+  }
   if (res) {                                       // ONE uniform branch around all residual loads (not one per row)
 #pragma unroll
     for (int i = 0; i < S; ++i) xv[i] += live ? res[base + i * S] : 0.f;
@@ -614,6 +638,27 @@ int afd_filt_act_fwd(const float* x, float* y, int B, int C, int H, int W,
   hipLaunchKernelGGL(gelu_inplace_gen, dim3(gs_grid(4 * e)), dim3(256), 0, s, U, 4 * e);
   hipLaunchKernelGGL(down2_fwd_gen, dim3(gs_grid(e)), dim3(256), 0, s, U, y, C, 2 * H, 2 * W, (long)C * 4 * H * W, (long)C * H * W, e, load_taps(taps_down, N), N);
   return check_launch("afd_filt_act_fwd");
+}
+
+size_t afd_filt_act_fwd_gn_supported(int C, int H, int W, int N) {
+  return (N == 3 && H == W && (H == 4 || H == 8 || H == 16) && (long)C * H <= 1024 && ((long)C * H) % 64 == 0) ? 1 : 0;
+}
+
+int afd_filt_act_fwd_gn(const float* x, float* y, int B, int C, int H, int W, float eps, float* stats_out,
+                        const float* gamma, const float* beta, const float* res,
+                        const float* taps_up, const float* taps_down, int N, afd_stream_t stream) {
+  if (int e = check_common("afd_filt_act_fwd_gn", x, y, B, C, H, W, taps_up, N)) return e;
+  AFD_REQUIRE(taps_down && stats_out, "afd_filt_act_fwd_gn: NULL pointer");
+  AFD_REQUIRE(afd_filt_act_fwd_gn_supported(C, H, W, N), "afd_filt_act_fwd_gn: shape (C=%d, %dx%d, N=%d) is not covered", C, H, W, N);
+  hipStream_t s = as_stream(stream);
+  const Taps3 u = load_taps3(taps_up), d = load_taps3(taps_down);
+  ensure_gelu_table(s);
+  const long planes = (long)B * C;
+  const dim3 grid((unsigned)B), block((unsigned)(C * H));                    // one workgroup = one sample: a lane per column of every plane
+  if (H == 4) hipLaunchKernelGGL((filt_act_fwd_n3<4, true, true>), grid, block, 0, s, x, y, planes, C, nullptr, gamma, beta, res, u, d, stats_out, eps);
+  else if (H == 8) hipLaunchKernelGGL((filt_act_fwd_n3<8, true, true>), grid, block, 0, s, x, y, planes, C, nullptr, gamma, beta, res, u, d, stats_out, eps);
+  else hipLaunchKernelGGL((filt_act_fwd_n3<16, true, true>), grid, block, 0, s, x, y, planes, C, nullptr, gamma, beta, res, u, d, stats_out, eps);
+  return check_launch("afd_filt_act_fwd_gn");
 }
 
 int afd_filt_act_bwd(const float* x, const float* dy, float* dv, int B, int C, int H, int W,

@@ -328,11 +328,16 @@ class GroupNormFiltAct(_Fn):
         B, C, H, W = x.shape
         stats = torch.empty(B, 2, device=x.device, dtype=torch.float32)
         L = lib()
-        L.afd_groupnorm1_fwd(_p(x), None, _p(stats), B, C, H * W, GN_EPS, None, None, None, 0, None, _stream())
         y = torch.empty_like(x)
-        ws = _act_ws(B, C, H, W, tu.N, 0, x.device)
-        L.afd_filt_act_fwd(_p(x), _p(y), B, C, H, W, _p(stats), _p(gamma), _p(beta), _p(res), tu.ptr, td.ptr, tu.N,
-                           _p(ws), _stream())
+        if L.afd_filt_act_fwd_gn_supported(C, H, W, tu.N):
+            # small samples: one workgroup holds a whole sample and computes the statistics itself (no statistics launch)
+            L.afd_filt_act_fwd_gn(_p(x), _p(y), B, C, H, W, GN_EPS, _p(stats), _p(gamma), _p(beta), _p(res), tu.ptr, td.ptr, tu.N,
+                                  _stream())
+        else:
+            L.afd_groupnorm1_fwd(_p(x), None, _p(stats), B, C, H * W, GN_EPS, None, None, None, 0, None, _stream())
+            ws = _act_ws(B, C, H, W, tu.N, 0, x.device)
+            L.afd_filt_act_fwd(_p(x), _p(y), B, C, H, W, _p(stats), _p(gamma), _p(beta), _p(res), tu.ptr, td.ptr, tu.N,
+                               _p(ws), _stream())
         ctx.save_for_backward(x, gamma, beta, res, stats)
         ctx.tu, ctx.td = tu, td
         return y

@@ -70,6 +70,13 @@ int afd_filt_act_fwd(const float* x, float* y, int B, int C, int H, int W,
                      const float* stats, const float* gamma, const float* beta, const float* res,
                      const float* taps_up, const float* taps_down, int N,
                      void* workspace, afd_stream_t stream);
+/* the forward INCLUDING the GroupNorm(1,C) statistics, for samples small enough that one workgroup holds one (C * H <= 1024
+ * threads, H = W in {4, 8, 16}, N = 3: afd_filt_act_fwd_gn_supported != 0): the statistics launch disappears; stats_out
+ * (B*2) receives {mean, rstd} for the backward entry points. */
+size_t afd_filt_act_fwd_gn_supported(int C, int H, int W, int N);
+int afd_filt_act_fwd_gn(const float* x, float* y, int B, int C, int H, int W, float eps, float* stats_out,
+                        const float* gamma, const float* beta, const float* res,
+                        const float* taps_up, const float* taps_down, int N, afd_stream_t stream);
 int afd_filt_act_bwd(const float* x, const float* dy, float* dv, int B, int C, int H, int W,
                      const float* stats, const float* gamma, const float* beta, const float* res,
                      const float* taps_up, const float* taps_down, int N,
