@@ -401,12 +401,16 @@ __global__ __launch_bounds__(STATS ? 1024 : 256) void filt_act_fwd_n3(const floa
 struct ActRowB { float t[4], dG[4]; float4 c[4]; };
 struct ActGB { float dU00, dU01, dU10, dU11, dU01l, dU11l; };
 
-template <int S, bool FULL>
-__global__ __launch_bounds__(256) void filt_act_bwd_n3(const float* __restrict__ x, const float* __restrict__ dy,
+// GNB (small samples, the workgroup IS one sample: blockDim = C * S, see the forward): the kernel also finishes GroupNorm's
+// backward -- dv stays in registers, the sample's two sums meet in LDS, dx = rstd (gamma dv - m1 - xhat m2) leaves instead of
+// dv (dv itself only when the residual branch needs it: dres = dv) -- so those sites have no gn_bwd_apply launch and no dv
+// round trip.
+template <int S, bool FULL, bool GNB = false>
+__global__ __launch_bounds__(GNB ? 1024 : 256) void filt_act_bwd_n3(const float* __restrict__ x, const float* __restrict__ dy,
                                                        float* __restrict__ dv, long planes, int C,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ res,
-                                                       float* __restrict__ part, Taps3 u, Taps3 d) {
+                                                       float* __restrict__ part, Taps3 u, Taps3 d, float* __restrict__ dx = nullptr) {
   __shared__ float4 Tb[kGeluPieces];                 // the GELU' pieces only
   load_gelu_table(Tb, kGeluPieces, kGeluPieces);
   Lane<S> L(planes);
@@ -421,6 +425,7 @@ __global__ __launch_bounds__(256) void filt_act_bwd_n3(const float* __restrict__
   float xv[S + 2], gv[S + 2];
   float a1 = 0.f, a2 = 0.f;                         // GroupNorm-backward plane sums: sum dv*xhat, sum dv
   float hx[S];                                      // xhat of the raw input (only needed for the partials)
+  float dvc[GNB ? S : 1];                           // GNB: this lane's column of dv
 #pragma unroll
   for (int i = 0; i < S; ++i) {
     const float h = live ? x[base + i * S] : 0.f;
@@ -466,7 +471,8 @@ __global__ __launch_bounds__(256) void filt_act_bwd_n3(const float* __restrict__
       const float out = u.k[0] * g.dU11 + u.k[1] * g.dU10 + u.k[2] * dU11l
                       + u.k[3] * g.dU01 + u.k[4] * g.dU00 + u.k[5] * dU01l
                       + u.k[6] * u11p + u.k[7] * u10p + u.k[8] * u11lp;
-      if (live) dv[base + (k - 2) * S] = out;
+      if (GNB) { dvc[k - 2] = out; if (dv) dv[base + (k - 2) * S] = out; }
+      else if (live) dv[base + (k - 2) * S] = out;
       a1 += out * hx[k - 2]; a2 += out;
       u10p = g.dU10; u11p = g.dU11; u11lp = dU11l;
     }
@@ -482,6 +488,14 @@ __global__ __launch_bounds__(256) void filt_act_bwd_n3(const float* __restrict__
       g.dU11l = lane_left(g.dU11);
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
+  if (GNB) {                                        // the sample's sums (every lane of the workgroup belongs to sample b)
+    __shared__ float red[16];
+    const float g = gamma ? gamma[c] : 1.f, n = (float)C * S * S;
+    const float m1 = block_sum(g * a2, red) / n;    // mean(gamma dv)
+    const float m2 = block_sum(g * a1, red) / n;    // mean(gamma dv xhat)
+#pragma unroll
+    for (int i = 0; i < S; ++i) dx[base + i * S] = rstd * (g * dvc[i] - m1 - hx[i] * m2);
   }
   if (part) {                                       // reduce over the S lanes that share the plane (fixed butterfly)
 #pragma unroll
@@ -659,6 +673,23 @@ int afd_filt_act_fwd_gn(const float* x, float* y, int B, int C, int H, int W, fl
   else if (H == 8) hipLaunchKernelGGL((filt_act_fwd_n3<8, true, true>), grid, block, 0, s, x, y, planes, C, nullptr, gamma, beta, res, u, d, stats_out, eps);
   else hipLaunchKernelGGL((filt_act_fwd_n3<16, true, true>), grid, block, 0, s, x, y, planes, C, nullptr, gamma, beta, res, u, d, stats_out, eps);
   return check_launch("afd_filt_act_fwd_gn");
+}
+
+int afd_filt_act_bwd_gn(const float* x, const float* dy, float* dx, float* dres, int B, int C, int H, int W, const float* stats,
+                        const float* gamma, const float* beta, const float* res, const float* taps_up, const float* taps_down, int N,
+                        float* gn_partials, afd_stream_t stream) {
+  if (int e = check_common("afd_filt_act_bwd_gn", x, dy, B, C, H, W, taps_up, N)) return e;
+  AFD_REQUIRE(dx && taps_down && stats && gn_partials, "afd_filt_act_bwd_gn: NULL pointer");
+  AFD_REQUIRE(afd_filt_act_fwd_gn_supported(C, H, W, N), "afd_filt_act_bwd_gn: shape (C=%d, %dx%d, N=%d) is not covered", C, H, W, N);
+  hipStream_t s = as_stream(stream);
+  const Taps3 u = load_taps3(taps_up), d = load_taps3(taps_down);
+  ensure_gelu_table(s);
+  const long planes = (long)B * C;
+  const dim3 grid((unsigned)B), block((unsigned)(C * H));
+  if (H == 4) hipLaunchKernelGGL((filt_act_bwd_n3<4, true, true>), grid, block, 0, s, x, dy, dres, planes, C, stats, gamma, beta, res, gn_partials, u, d, dx);
+  else if (H == 8) hipLaunchKernelGGL((filt_act_bwd_n3<8, true, true>), grid, block, 0, s, x, dy, dres, planes, C, stats, gamma, beta, res, gn_partials, u, d, dx);
+  else hipLaunchKernelGGL((filt_act_bwd_n3<16, true, true>), grid, block, 0, s, x, dy, dres, planes, C, stats, gamma, beta, res, gn_partials, u, d, dx);
+  return check_launch("afd_filt_act_bwd_gn");
 }
 
 int afd_filt_act_bwd(const float* x, const float* dy, float* dv, int B, int C, int H, int W,

@@ -348,6 +348,23 @@ class GroupNormFiltAct(_Fn):
         B, C, H, W = x.shape
         dy = _c(dy)
         L = lib()
+        if L.afd_filt_act_fwd_gn_supported(C, H, W, ctx.tu.N):
+            # small samples: one workgroup holds a sample, the same launch finishes GroupNorm's backward (dx leaves instead of dv)
+            dx = torch.empty_like(x)
+            dres = torch.empty_like(x) if res is not None else None
+            part = torch.empty(B * C * 2, device=x.device, dtype=torch.float32)
+            L.afd_filt_act_bwd_gn(_p(x), _p(dy), _p(dx), _p(dres), B, C, H, W, _p(stats), _p(gamma), _p(beta), _p(res),
+                                  ctx.tu.ptr, ctx.td.ptr, ctx.tu.N, _p(part), _stream())
+            dg, db, acc, (dgamma, dbeta) = _gn_param_targets(C, gamma, beta, x.device)
+            if acc and _GradMode.side is not None:                     # the two column sums: off the critical path
+                pg, pb = _p(dg), _p(db)
+                defer_to_side_stream(lambda st, part=part, pg=pg, pb=pb: L.afd_colsum2(_p(part), pg, pb, B, C, 1, st), part,
+                                     writes=(gamma, beta))
+            else:
+                L.afd_colsum2(_p(part), _p(dg), _p(db), B, C, acc, _stream())
+                if acc:
+                    _wrote(gamma, beta)
+            return dx, dgamma, dbeta, dres, None, None
         dv = torch.empty_like(x)
         ws = _act_ws(B, C, H, W, ctx.tu.N, 1, x.device)
         part = torch.empty(B * C * 2, device=x.device, dtype=torch.float32)

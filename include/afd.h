@@ -77,6 +77,12 @@ size_t afd_filt_act_fwd_gn_supported(int C, int H, int W, int N);
 int afd_filt_act_fwd_gn(const float* x, float* y, int B, int C, int H, int W, float eps, float* stats_out,
                         const float* gamma, const float* beta, const float* res,
                         const float* taps_up, const float* taps_down, int N, afd_stream_t stream);
+/* ... and the backward that also finishes GroupNorm's backward for such samples: dx = dL/dx of the GroupNorm INPUT leaves
+ * instead of dv (dres, or NULL: also write dv = the residual branch's gradient); gn_partials (B,2,C) as in afd_filt_act_bwd --
+ * the caller still folds them into dgamma / dbeta (afd_colsum2).  No afd_groupnorm1_bwd call for these sites. */
+int afd_filt_act_bwd_gn(const float* x, const float* dy, float* dx, float* dres, int B, int C, int H, int W, const float* stats,
+                        const float* gamma, const float* beta, const float* res, const float* taps_up, const float* taps_down, int N,
+                        float* gn_partials, afd_stream_t stream);
 int afd_filt_act_bwd(const float* x, const float* dy, float* dv, int B, int C, int H, int W,
                      const float* stats, const float* gamma, const float* beta, const float* res,
                      const float* taps_up, const float* taps_down, int N,
