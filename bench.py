@@ -120,6 +120,11 @@ def kernel_table(dev, B):
         st = torch.zeros(B, 2, device=dev); st[:, 1] = 1
         g = torch.ones(C, device=dev); be = torch.zeros(C, device=dev)
         part = torch.empty(B * C * 2, device=dev); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+        if L.afd_filt_act_fwd_gn_supported(C, S, S, 3):
+            # small samples: the statistics and GroupNorm's backward ride in the activation's own launches (as ops.py calls them)
+            tf = ev_time(lambda: L.afd_filt_act_fwd_gn(P(x), P(y), B, C, S, S, 1e-5, P(st), P(g), P(be), None, tk.ptr, tk.ptr, 3, s))
+            tb = ev_time(lambda: L.afd_filt_act_bwd_gn(P(x), P(y), P(dx), None, B, C, S, S, P(st), P(g), P(be), None, tk.ptr, tk.ptr, 3, P(part), s))
+            return tf, tb, None, None
         tf = ev_time(lambda: L.afd_filt_act_fwd(P(x), P(y), B, C, S, S, P(st), P(g), P(be), None, tk.ptr, tk.ptr, 3, None, s))
         tb = ev_time(lambda: L.afd_filt_act_bwd(P(x), P(y), P(dv), B, C, S, S, P(st), P(g), P(be), None, tk.ptr, tk.ptr, 3, None, P(part), s))
         tg = ev_time(lambda: L.afd_groupnorm1_fwd(P(x), None, P(st), B, C, S * S, 1e-5, None, None, None, 0, None, s))
@@ -130,8 +135,9 @@ def kernel_table(dev, B):
         e = float(B) * C * S * S
         add("filt_act_fwd_n3", tf, bytes_=8 * e, bound="hbm")
         add("filt_act_bwd_n3", tb, bytes_=12 * e, bound="hbm")
-        add("groupnorm1_stats", tg, bytes_=4 * e, bound="hbm")
-        add("groupnorm1_bwd_apply", ta, bytes_=12 * e, bound="hbm")
+        if tg is not None:
+            add("groupnorm1_stats", tg, bytes_=4 * e, bound="hbm")
+            add("groupnorm1_bwd_apply", ta, bytes_=12 * e, bound="hbm")
     seen = {}
 
     def gn_site(C, S):
