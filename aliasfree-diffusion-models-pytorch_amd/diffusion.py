@@ -1,7 +1,7 @@
 """F12-F17: the DDPM process (modules/ddpm_models.py:301-436) over the HIP kernels.
 
-Bit-exactness: the schedule tables are built on the host in the reference's op order (fp32
-linspace, sequential cumprod); `sample_timesteps` draws from torch's CPU generator exactly like
+Bit-exactness: the schedule tables are built on the host with the reference's own torch calls (fp32
+linspace; torch.cumprod, which on the CPU accumulates fp32 inputs in double -- DESIGN.md section 4); `sample_timesteps` draws from torch's CPU generator exactly like
 the reference; noise_images / the denoise update / the uint8 quantisation are bit-exact HIP
 restatements (csrc/ddpm.hip).  The sampling loop stays on the device: no per-step H2D copy of `t`
 (the reference does one per step, :362) and no per-step host sync.
@@ -44,7 +44,7 @@ class Diffusion:
         self.img_size, self.device = img_size, device
         beta = self.prepare_noise_schedule()                    # host fp32
         alpha = 1.0 - beta
-        alpha_hat = torch.cumprod(alpha, dim=0)                 # sequential fp32 product on the host
+        alpha_hat = torch.cumprod(alpha, dim=0)                 # host ATen cumprod, as the reference (:309): accumulates in double, rounds to fp32
         self.beta, self.alpha, self.alpha_hat = beta.to(device), alpha.to(device), alpha_hat.to(device)
         self.filter = None
         self._t_cache = {}

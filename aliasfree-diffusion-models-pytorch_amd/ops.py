@@ -537,8 +537,8 @@ class Conv(_Fn):
                 L.afd_conv3x3_wino_dgrad(_p(dy), _p(w), _p(dx), _p(dfork), B, Cin, Cout, H, W, _p(u), ready, _stream())
             else:
                 L.afd_conv_dgrad(_p(dy), _p(w), _p(dx), B, Cin, Cout, H, W, ks, _stream())
-                if dfork is not None:
-                    dx = dx + dfork
+                if dfork is not None:                      # (the direct kernels have no add-to-dx epilogue)
+                    L.afd_add(_p(dx), _p(dfork), _p(dx), dx.numel(), _stream())
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             nbytes = L.afd_conv_wgrad_workspace_bytes(B, Cin, Cout, H, W, ks)
             ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
@@ -957,54 +957,59 @@ class SiluLinear(_Fn):
         return dtemb, dw, db
 
 
-class SiluLinearBatched(_Fn):
+def silu_linear_batched(temb, layers):
     """The emb_layer of several stages (each nn.Sequential(nn.SiLU(), nn.Linear(emb_dim, C_i)), ddpm_utils.py:208-214) on the SAME
-    time embedding in one launch: forward(temb, w_0, b_0, w_1, b_1, ...) -> (out_0, out_1, ...).  The input exists as soon as
-    the UNet forward starts, so one launch replaces six small dependent ones; the parameter gradients go the way
-    SiluLinear's do.  temb must not need a gradient (the conditional model keeps the per-stage op)."""
-
-    @staticmethod
-    def forward(ctx, temb, *wb):
-        import ctypes, struct
-        ws, bs = wb[0::2], wb[1::2]
-        _chk(temb, *ws, *bs)
-        temb = _c(temb)
-        B, K = temb.shape
+    time embedding: ONE forward launch for all of them (the input exists as soon as the UNet forward starts, so one launch
+    replaces six small dependent ones) -> [out_0, out_1, ...].  `layers` = [(weight, bias), ...]; temb must not need a gradient
+    (the conditional model keeps the per-stage op).  Backward stays PER STAGE: every output leaves through its own autograd
+    node (SiluLinearPre), which produces and reports that stage's parameter gradients as soon as its dout arrives -- one
+    node for all six would hold every stage's gradient (and with it three of the four data-parallel buckets) back until the
+    first encoder stage's backward."""
+    import ctypes, struct
+    ws, bs = [w for w, _ in layers], [b for _, b in layers]
+    _chk(temb, *ws, *bs)
+    temb = _c(temb)
+    B, K = temb.shape
+    with torch.no_grad():
         outs = [torch.empty(B, w.shape[0], device=temb.device, dtype=torch.float32) for w in ws]
-        desc = b"".join(struct.pack("<QQQi4x", _p(w) or 0, _p(b) or 0, _p(o), w.shape[0]) for w, b, o in zip(ws, bs, outs))
-        buf = ctypes.create_string_buffer(desc, len(desc))
-        lib().afd_silu_linear_fwd_batched(_p(temb), ctypes.addressof(buf), len(ws), B, K, _stream())
-        ctx.save_for_backward(temb, *ws)
-        ctx.params = [(w if isinstance(w, torch.nn.Parameter) else None, b if isinstance(b, torch.nn.Parameter) else None)
-                      for w, b in zip(ws, bs)]
-        return tuple(outs)
+    desc = b"".join(struct.pack("<QQQi4x", _p(w) or 0, _p(b) or 0, _p(o), w.shape[0]) for w, b, o in zip(ws, bs, outs))
+    buf = ctypes.create_string_buffer(desc, len(desc))
+    lib().afd_silu_linear_fwd_batched(_p(temb), ctypes.addressof(buf), len(ws), B, K, _stream())
+    if not torch.is_grad_enabled():
+        return outs
+    return [SiluLinearPre.apply(o, temb, w, b) for o, w, b in zip(outs, ws, bs)]
+
+
+class SiluLinearPre(_Fn):
+    """Autograd node of ONE stage's emb_layer whose forward value was computed by silu_linear_batched: forward hands the
+    precomputed output on, backward is SiluLinear's parameter-gradient part."""
 
     @staticmethod
-    def backward(ctx, *douts):
-        temb, *ws = ctx.saved_tensors
+    def forward(ctx, out, temb, w, bias):
+        ctx.save_for_backward(temb, w)
+        ctx.params = (w if isinstance(w, torch.nn.Parameter) else None, bias if isinstance(bias, torch.nn.Parameter) else None)
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        temb, w = ctx.saved_tensors
         B, K = temb.shape
-        grads = [None]
-        for w, dout, (wp, bp) in zip(ws, douts, ctx.params):
-            N = w.shape[0]
-            if dout is None:
-                grads += [None, None]
-                continue
-            dout = _c(dout)
-            if _direct(wp, bp):
-                if _GradMode.side is not None:                     # parameter gradients only: off the critical path
-                    pw, pb = _p(wp.grad), _p(bp.grad)
-                    defer_to_side_stream(lambda st, temb=temb, w=w, dout=dout, pw=pw, pb=pb, N=N: lib().afd_silu_linear_bwd(
-                        _p(temb), _p(w), _p(dout), pw, pb, None, B, K, N, 1, st), temb, w, dout, writes=(wp, bp))
-                else:
-                    lib().afd_silu_linear_bwd(_p(temb), _p(w), _p(dout), _p(wp.grad), _p(bp.grad), None, B, K, N, 1, _stream())
-                    _wrote(wp, bp)
-                grads += [None, None]
-                continue
-            dw = torch.empty_like(w)
-            db = torch.empty(N, device=w.device, dtype=torch.float32)
-            lib().afd_silu_linear_bwd(_p(temb), _p(w), _p(dout), _p(dw), _p(db), None, B, K, N, 0, _stream())
-            grads += [dw, db]
-        return tuple(grads)
+        N = w.shape[0]
+        dout = _c(dout)
+        wp, bp = ctx.params
+        if _direct(wp, bp):
+            if _GradMode.side is not None:                         # parameter gradients only: off the critical path
+                pw, pb = _p(wp.grad), _p(bp.grad)
+                defer_to_side_stream(lambda st, temb=temb, w=w, dout=dout: lib().afd_silu_linear_bwd(
+                    _p(temb), _p(w), _p(dout), pw, pb, None, B, K, N, 1, st), temb, w, dout, writes=(wp, bp))
+            else:
+                lib().afd_silu_linear_bwd(_p(temb), _p(w), _p(dout), _p(wp.grad), _p(bp.grad), None, B, K, N, 1, _stream())
+                _wrote(wp, bp)
+            return None, None, None, None
+        dw = torch.empty_like(w)
+        db = torch.empty(N, device=w.device, dtype=torch.float32)
+        lib().afd_silu_linear_bwd(_p(temb), _p(w), _p(dout), _p(dw), _p(db), None, B, K, N, 0, _stream())
+        return None, None, dw, db
 
 
 # ---------------------------------------------------------------------------------------------

@@ -151,7 +151,9 @@ class GradAllReduce:
                 self._bucket_of[id(p_)] = k
                 self._count[k] += 1
         self._left, self._seen, self._works, self._launched = list(self._count), set(), [], set()
-        self.overlapped_last_step = 0
+        self.overlapped_last_step = 0          # buckets whose all-reduce started while backward was still running
+        self.started_before_finish = 0         # ... plus those started by the final flush of the weight-gradient queue
+        self._in_backward = None
 
     @staticmethod
     def _module_edges(fp, model, nb):
@@ -176,6 +178,12 @@ class GradAllReduce:
     # -- readiness bookkeeping (called during backward) ------------------------------------------
     def begin_step(self):
         self._left, self._seen, self._works, self._launched = list(self._count), set(), [], set()
+        self._in_backward = None
+
+    def backward_done(self):
+        """Called when autograd's backward has returned (before the last queued weight-gradient launches are flushed): the
+        buckets started up to here really overlapped backward."""
+        self._in_backward = len(self._launched)
 
     def wrote(self, params):
         """The gradient of each given parameter has been fully written by work already ENQUEUED on the current stream or on
@@ -215,7 +223,8 @@ class GradAllReduce:
         into the mean (handed to AdamW as grad_scale)."""
         if self.world == 1:
             return 1.0
-        self.overlapped_last_step = len(self._launched)
+        self.started_before_finish = len(self._launched)
+        self.overlapped_last_step = self._in_backward if self._in_backward is not None else len(self._launched)
         for k in reversed(range(len(self.slices))):      # last layers first
             self._launch(k)
         for w, h, buf in self._works:
@@ -280,6 +289,8 @@ class TrainStep:
             with ops.inplace_param_grads(self.wgrad_stream, self.wgrad_batch,   # weight gradients add straight into the flat .grad views
                                          on_write=self.ddp.wrote if overlap else None):
                 loss.backward()
+                if overlap:
+                    self.ddp.backward_done()
         finally:
             if W.recording is not None and W.recording is self._wino_requests:
                 W.recording = None

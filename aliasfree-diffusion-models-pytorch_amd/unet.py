@@ -104,8 +104,8 @@ class UNet(nn.Module):
             t = ops.EmbedAdd.apply(t, self.label_emb.weight, y.to(x.device))        # t += label_emb(y)   (:276-277)
         if not t.requires_grad:                       # the six stages' emb_layer(t) in one launch (t is ready now)
             stages = (self.down1, self.down2, self.down3, self.up1, self.up2, self.up3)
-            wb = [p for s in stages for p in (s.emb_layer[1].weight, s.emb_layer[1].bias)]
-            for s, e in zip(stages, ops.SiluLinearBatched.apply(t, *wb)):
+            layers = [(s.emb_layer[1].weight, s.emb_layer[1].bias) for s in stages]
+            for s, e in zip(stages, ops.silu_linear_batched(t, layers)):
                 s._emb_pre = (t, e)
         x1 = self.inc(x)
         x2 = self.sa1(self.down1(x1, t))

@@ -74,13 +74,22 @@ EMB = [64, 128, 128, 64, 32, 32]                         # time-embedding Linear
 N_PARAMS = 5897155
 
 
-def kernel_table(dev, B):
-    """Times EVERY kernel family of one Config-D train step (forward + backward + optimiser) over its real shapes, each
-    through the C-ABI entry point the autograd shells call, with HIP events on the launch stream.  Per family: launches,
-    ms per step, algorithmic flops or bytes, the bound it is priced against and the fraction reached."""
+def kernel_table(dev, B, mode="train"):
+    """Times EVERY kernel family of one Config-D train step (mode "train": forward + backward + optimiser) or of one denoise
+    step of Diffusion.sample (mode "sample": the UNet forward in its inference form -- no saved activations in the token
+    chains -- plus the DDPM update; ddpm_models.py:352-386) over its real shapes, each through the C-ABI entry point the
+    autograd shells call, with HIP events on the launch stream.  Per family: launches, ms per step, algorithmic flops or
+    bytes, the bound it is priced against and the fraction reached.
+
+    `frac` of the matrix-pipe families is the EXECUTED fraction: the time the pipe would need, at the peak of the
+    instruction each launch really issues, for the products it issues (bf16x3: 6 bf16 products per fp32 product against
+    the 2500 TFLOP/s bf16 peak; Winograd: 16/36 of the products against the 157.3 TFLOP/s fp32 peak; direct fp32 MFMA:
+    all of them against 157.3) over the measured time -- never above 1.  The algorithmic direct-form rate against the
+    fp32 matrix peak is kept beside it as `frac_algorithmic_vs_fp32_peak` (it exceeds 1 where bf16x3 pays off)."""
     import afdm
     from afdm import ops
     L, s = afdm.lib(), torch.cuda.current_stream().cuda_stream
+    train = mode == "train"
     rows = {}
     P = lambda t: None if t is None else t.data_ptr()
 
@@ -105,9 +114,11 @@ def kernel_table(dev, B):
                 "direct": fl / (MFMA_F32_PEAK_TF * 1e12)}[form]
 
     for (ci, co, S) in CONV3:
-        tf, td, tw, ff, fd, fw = cached(seen, (ci, co, S), lambda: conv_layer_times(L, s, dev, B, ci, co, S))
+        tf, td, tw, ff, fd, fw = cached(seen, (ci, co, S), lambda: conv_layer_times(L, s, dev, B, ci, co, S, fwd_only=not train))
         fl = 2.0 * B * S * S * ci * co * 9              # algorithmic (direct-form) flops of one pass
         add("conv3x3_fwd", tf, fl, bound="mfma", pipe_s=pipe_s(fl, ff), **{ff: 1})
+        if not train:
+            continue
         if ci > 3:
             add("conv3x3_dgrad", td, fl, bound="mfma", pipe_s=pipe_s(fl, fd), **{fd: 1})
         add("conv3x3_wgrad", tw, fl, bound="mfma", pipe_s=pipe_s(fl, fw), **{fw: 1})
@@ -123,21 +134,25 @@ def kernel_table(dev, B):
         if L.afd_filt_act_fwd_gn_supported(C, S, S, 3):
             # small samples: the statistics and GroupNorm's backward ride in the activation's own launches (as ops.py calls them)
             tf = ev_time(lambda: L.afd_filt_act_fwd_gn(P(x), P(y), B, C, S, S, 1e-5, P(st), P(g), P(be), None, tk.ptr, tk.ptr, 3, s))
-            tb = ev_time(lambda: L.afd_filt_act_bwd_gn(P(x), P(y), P(dx), None, B, C, S, S, P(st), P(g), P(be), None, tk.ptr, tk.ptr, 3, P(part), s))
+            tb = ev_time(lambda: L.afd_filt_act_bwd_gn(P(x), P(y), P(dx), None, B, C, S, S, P(st), P(g), P(be), None, tk.ptr, tk.ptr, 3, P(part), s)) if train else 0.0
             return tf, tb, None, None
         tf = ev_time(lambda: L.afd_filt_act_fwd(P(x), P(y), B, C, S, S, P(st), P(g), P(be), None, tk.ptr, tk.ptr, 3, None, s))
-        tb = ev_time(lambda: L.afd_filt_act_bwd(P(x), P(y), P(dv), B, C, S, S, P(st), P(g), P(be), None, tk.ptr, tk.ptr, 3, None, P(part), s))
         tg = ev_time(lambda: L.afd_groupnorm1_fwd(P(x), None, P(st), B, C, S * S, 1e-5, None, None, None, 0, None, s))
+        if not train:
+            return tf, 0.0, tg, 0.0
+        tb = ev_time(lambda: L.afd_filt_act_bwd(P(x), P(y), P(dv), B, C, S, S, P(st), P(g), P(be), None, tk.ptr, tk.ptr, 3, None, P(part), s))
         ta = ev_time(lambda: L.afd_groupnorm1_bwd(P(x), P(dv), P(st), B, C, S * S, P(g), P(be), None, 0, P(dx), None, P(part), None, 1, P(dg), P(db), 1, s))
         return tf, tb, tg, ta
     for (C, S) in ACT_SITES:
         tf, tb, tg, ta = cached(seen, (C, S), lambda: act_site(C, S))
         e = float(B) * C * S * S
         add("filt_act_fwd_n3", tf, bytes_=8 * e, bound="hbm")
-        add("filt_act_bwd_n3", tb, bytes_=12 * e, bound="hbm")
+        if train:
+            add("filt_act_bwd_n3", tb, bytes_=12 * e, bound="hbm")
         if tg is not None:
             add("groupnorm1_stats", tg, bytes_=4 * e, bound="hbm")
-            add("groupnorm1_bwd_apply", ta, bytes_=12 * e, bound="hbm")
+            if train:
+                add("groupnorm1_bwd_apply", ta, bytes_=12 * e, bound="hbm")
     seen = {}
 
     def gn_site(C, S):
@@ -146,21 +161,23 @@ def kernel_table(dev, B):
         emb = torch.randn(B, C, device=dev); demb = torch.empty(B, C, device=dev)
         part = torch.empty(B * C * 2, device=dev); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
         tf = ev_time(lambda: L.afd_groupnorm1_fwd(P(x), P(y), P(st), B, C, S * S, 1e-5, P(g), P(be), None, 0, P(emb), s))
-        tb = ev_time(lambda: L.afd_groupnorm1_bwd(P(x), P(y), P(st), B, C, S * S, P(g), P(be), None, 0, P(dx), None, P(part), P(demb), 0, P(dg), P(db), 1, s))
+        tb = ev_time(lambda: L.afd_groupnorm1_bwd(P(x), P(y), P(st), B, C, S * S, P(g), P(be), None, 0, P(dx), None, P(part), P(demb), 0, P(dg), P(db), 1, s)) if train else 0.0
         return tf, tb
     for (C, S) in GN_PLAIN:
         tf, tb = cached(seen, (C, S), lambda: gn_site(C, S))
         e = float(B) * C * S * S
         add("groupnorm1_fwd_full", tf, bytes_=8 * e, bound="hbm")
-        add("groupnorm1_bwd_full", tb, bytes_=20 * e, launches=2, bound="hbm")          # plane sums (x, dy) + apply (x, dy -> dx)
+        if train:
+            add("groupnorm1_bwd_full", tb, bytes_=20 * e, launches=2, bound="hbm")          # plane sums (x, dy) + apply (x, dy -> dx)
     # ---- block-level filtered resampling (F2 / F3) and the concat copy --------------------------------------------
     for (C, S) in RESAMPLE:
         x = torch.randn(B, C, S, S, device=dev); y = torch.empty(B, C, S // 2, S // 2, device=dev)
         e_hi, e_lo = float(B) * C * S * S, float(B) * C * S * S / 4
         add("filt_down2_fwd", ev_time(lambda: L.afd_filt_down2_fwd(P(x), P(y), B, C, S, S, 0, 0, tk.ptr, 3, s)), bytes_=4 * (e_hi + e_lo), bound="hbm")
-        add("filt_down2_bwd", ev_time(lambda: L.afd_filt_down2_bwd(P(y), P(x), B, C, S, S, 0, 0, tk.ptr, 3, s)), bytes_=4 * (e_hi + e_lo), bound="hbm")
         add("filt_up2_fwd", ev_time(lambda: L.afd_filt_up2_fwd(P(y), P(x), B, C, S // 2, S // 2, 0, 0, tk.ptr, 3, s)), bytes_=4 * (e_hi + e_lo), bound="hbm")
-        add("filt_up2_bwd", ev_time(lambda: L.afd_filt_up2_bwd(P(x), P(y), B, C, S // 2, S // 2, 0, 0, tk.ptr, 3, s)), bytes_=4 * (e_hi + e_lo), bound="hbm")
+        if train:
+            add("filt_down2_bwd", ev_time(lambda: L.afd_filt_down2_bwd(P(y), P(x), B, C, S, S, 0, 0, tk.ptr, 3, s)), bytes_=4 * (e_hi + e_lo), bound="hbm")
+            add("filt_up2_bwd", ev_time(lambda: L.afd_filt_up2_bwd(P(x), P(y), B, C, S // 2, S // 2, 0, 0, tk.ptr, 3, s)), bytes_=4 * (e_hi + e_lo), bound="hbm")
         # (forward only: the backward hands the skip's gradient on as a view of the concat gradient)
         add("concat_copy", ev_time(lambda: L.afd_copy_batched(P(x), P(x), B, C * S * S, 0, 0, s)), bytes_=8 * e_hi, launches=1, bound="hbm")
         del x, y
@@ -170,10 +187,11 @@ def kernel_table(dev, B):
         qkv = torch.randn(B, 3 * C, S, S, device=dev); o = torch.empty(B, C, S, S, device=dev)
         lse = torch.empty(B, 4, Lq, device=dev); dq = torch.empty_like(qkv); dl = torch.empty_like(lse)
         tf = ev_time(lambda: L.afd_attn_fwd(P(qkv), P(o), P(lse), B, 4, C // 4, Lq, s), reps=3, warm=1)
-        tb = ev_time(lambda: L.afd_attn_bwd(P(qkv), P(o), P(o), P(lse), P(dq), P(dl), B, 4, C // 4, Lq, s), reps=3, warm=1)
         fl = 4.0 * B * Lq * Lq * C
         add("attn_fwd", tf, fl, bound="mfma")
-        add("attn_bwd", tb, 2.5 * fl, launches=2, bound="mfma")
+        if train:
+            tb = ev_time(lambda: L.afd_attn_bwd(P(qkv), P(o), P(o), P(lse), P(dq), P(dl), B, 4, C // 4, Lq, s), reps=3, warm=1)
+            add("attn_bwd", tb, 2.5 * fl, launches=2, bound="mfma")
         # token-wise chains
         x = torch.randn(B, C, S, S, device=dev)
         mk = lambda *sh: torch.randn(*sh, device=dev) * 0.1
@@ -182,8 +200,18 @@ def kernel_table(dev, B):
         h, st = torch.empty_like(x), torch.empty(B, Lq, 2, device=dev)
         a, f, u, g, out = (torch.empty_like(x) for _ in range(5))
         st2 = torch.empty(B, Lq, 2, device=dev)
-        du, df, da, datt, dh, dx = (torch.empty_like(x) for _ in range(6))
         e, flc = 4.0 * B * C * Lq, 2.0 * B * Lq * C * C
+        if not train:
+            # inference forms (ops.AttnHead / AttnTail under no_grad): nothing is saved for a backward -- head reads x, writes qkv;
+            # tail reads att and x, writes out
+            assert L.afd_tok_supported(C)
+            add("tok_head_fwd", ev_time(lambda: L.afd_tok_head_fwd(P(x), P(g1), P(b1_), P(w_in), P(b_in), None, None, P(qkv), B, C, Lq, 1e-5, s)),
+                3 * flc, 4 * e, bound="hbm")
+            add("tok_tail_fwd", ev_time(lambda: L.afd_tok_tail_fwd(P(o), P(x), P(wo), P(bo), P(g2), P(be2), P(w1), P(b1), P(w2), P(b2), None, None, None, None,
+                                                                    None, P(out), B, C, Lq, 1e-5, s)), 3 * flc, 3 * e, bound="hbm")
+            del qkv, o, lse, dq, x, h, a, f, u, g, out
+            continue
+        du, df, da, datt, dh, dx = (torch.empty_like(x) for _ in range(6))
         if L.afd_tok_supported(C):
             add("tok_head_fwd", ev_time(lambda: L.afd_tok_head_fwd(P(x), P(g1), P(b1_), P(w_in), P(b_in), P(h), P(st), P(qkv), B, C, Lq, 1e-5, s)),
                 3 * flc, 5 * e, bound="hbm")
@@ -201,34 +229,51 @@ def kernel_table(dev, B):
         add("layernorm_params", 2 * ev_time(lambda: L.afd_layernorm_c_bwd_params(P(x), P(dh), P(st), B, C, Lq, P(part), P(dbc), P(dbc), 0, s)), bytes_=2 * 2 * e,
             launches=2, bound="hbm")
         del qkv, o, lse, dq, x, h, a, f, u, g, out, du, df, da, datt, dh, dx
-    # ---- time embedding, loss, optimiser -------------------------------------------------------------------------
+    # ---- time embedding, loss, optimiser / DDPM update ---------------------------------------------------------------
     temb = torch.randn(B, 256, device=dev)
-    for C in EMB:
-        w, b = torch.randn(C, 256, device=dev), torch.randn(C, device=dev)
-        o, dw, db = torch.empty(B, C, device=dev), torch.empty(C, 256, device=dev), torch.empty(C, device=dev)
-        add("silu_linear_fwd", ev_time(lambda: L.afd_silu_linear_fwd(P(temb), P(w), P(b), P(o), B, 256, C, s)), 2.0 * B * 256 * C, bound="hbm",
-            bytes_=4.0 * (B * 256 + 256 * C + B * C))
-        add("silu_linear_bwd", ev_time(lambda: L.afd_silu_linear_bwd(P(temb), P(w), P(o), P(dw), P(db), None, B, 256, C, 0, s)), 2.0 * B * 256 * C, bound="hbm",
-            bytes_=4.0 * (B * 256 + 256 * C + B * C))
     n_img = B * 3 * 32 * 32
     xi, ei = torch.randn(n_img, device=dev), torch.randn(n_img, device=dev)
-    loss, wsl = torch.empty(1, device=dev), torch.empty(4096, device=dev)
-    add("mse_fwd_bwd", ev_time(lambda: (L.afd_mse_fwd(P(xi), P(ei), P(loss), P(wsl), n_img, s), L.afd_mse_bwd(P(xi), P(ei), P(loss), P(xi), n_img, s))),
-        bytes_=4.0 * 5 * n_img, launches=2, bound="hbm")
-    pf, gf, mf, vf = (torch.zeros(N_PARAMS, device=dev) for _ in range(4))
-    stt = torch.zeros(4, device=dev)
+    if train:
+        for C in EMB:
+            w, b = torch.randn(C, 256, device=dev), torch.randn(C, device=dev)
+            o, dw, db = torch.empty(B, C, device=dev), torch.empty(C, 256, device=dev), torch.empty(C, device=dev)
+            add("silu_linear_fwd", ev_time(lambda: L.afd_silu_linear_fwd(P(temb), P(w), P(b), P(o), B, 256, C, s)), 2.0 * B * 256 * C, bound="hbm",
+                bytes_=4.0 * (B * 256 + 256 * C + B * C))
+            add("silu_linear_bwd", ev_time(lambda: L.afd_silu_linear_bwd(P(temb), P(w), P(o), P(dw), P(db), None, B, 256, C, 0, s)), 2.0 * B * 256 * C, bound="hbm",
+                bytes_=4.0 * (B * 256 + 256 * C + B * C))
+        loss, wsl = torch.empty(1, device=dev), torch.empty(4096, device=dev)
+        add("mse_fwd_bwd", ev_time(lambda: (L.afd_mse_fwd(P(xi), P(ei), P(loss), P(wsl), n_img, s), L.afd_mse_bwd(P(xi), P(ei), P(loss), P(xi), n_img, s))),
+            bytes_=4.0 * 5 * n_img, launches=2, bound="hbm")
+        pf, gf, mf, vf = (torch.zeros(N_PARAMS, device=dev) for _ in range(4))
+        stt = torch.zeros(4, device=dev)
 
-    def adam():
-        L.afd_adamw_tick(P(stt), 0.9, 0.999, s)
-        L.afd_adamw_step(P(pf), P(gf), P(mf), P(vf), N_PARAMS, P(stt), 3e-4, 0.9, 0.999, 1e-8, 0.01, 1.0, s)
-    add("adamw", ev_time(adam), bytes_=28.0 * N_PARAMS, launches=2, bound="hbm")
+        def adam():
+            L.afd_adamw_tick(P(stt), 0.9, 0.999, s)
+            L.afd_adamw_step(P(pf), P(gf), P(mf), P(vf), N_PARAMS, P(stt), 3e-4, 0.9, 0.999, 1e-8, 0.01, 1.0, s)
+        add("adamw", ev_time(adam), bytes_=28.0 * N_PARAMS, launches=2, bound="hbm")
+    else:
+        import ctypes, struct
+        ws_ = [torch.randn(C, 256, device=dev) for C in EMB]
+        bs_ = [torch.randn(C, device=dev) for C in EMB]
+        os_ = [torch.empty(B, C, device=dev) for C in EMB]
+        desc = b"".join(struct.pack("<QQQi4x", P(w), P(b), P(o), w.shape[0]) for w, b, o in zip(ws_, bs_, os_))
+        buf = ctypes.create_string_buffer(desc, len(desc))
+        add("silu_linear_fwd_batched", ev_time(lambda: L.afd_silu_linear_fwd_batched(P(temb), ctypes.addressof(buf), len(EMB), B, 256, s)),
+            2.0 * B * 256 * sum(EMB), bytes_=4.0 * (B * 256 + (256 + B) * sum(EMB)), bound="hbm")
+        x32 = torch.randn(B, 32, 32, 32, device=dev); w_out = torch.randn(3, 32, 1, 1, device=dev); b_out = torch.randn(3, device=dev)
+        y3 = torch.empty(B, 3, 32, 32, device=dev)
+        add("outc_1x1", ev_time(lambda: L.afd_conv_fwd(P(x32), P(w_out), P(b_out), None, P(y3), B, 32, 3, 32, 32, 1, 0, s)), bytes_=4.0 * B * 35 * 1024, bound="hbm")
+        al = torch.linspace(0.9, 0.99, 1000, device=dev)
+        nz, xo = torch.empty(n_img, device=dev), torch.empty(n_img, device=dev)
+        add("denoise_step", ev_time(lambda: L.afd_denoise_step(P(xi), P(ei), P(nz), P(al), P(al), P(al), 500, P(xo), n_img, s)), bytes_=16.0 * n_img, bound="hbm")
+        add("randn (torch device generator: the per-step noise draw)", ev_time(lambda: nz.normal_()), bytes_=4.0 * n_img, bound="hbm")
     # ---- Config E: the per-step rotation of sampling (not part of the train step) -----------------------------------
     xr = torch.randn(B, 3, 32, 32, device=dev)
     t_rot = ev_time(lambda: ops.rotate_spline3_wrap(xr, 0.09))
     torch.cuda.synchronize()
-    pmc = {}
+    pmc, pmc_path = {}, "profiles/pmc_families.json" if train else "profiles/pmc_sample_families.json"
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_families.json")))
+        pmc = json.load(open(os.path.join(ROOT, pmc_path)))
     except Exception:
         pass
     out = []
@@ -236,25 +281,30 @@ def kernel_table(dev, B):
         sec = r["ms"] * 1e-3
         tf = r["flops"] / sec / 1e12 if r["flops"] else None
         gb = r["bytes"] / sec / 1e9 if r["bytes"] else None
-        frac = (tf / MFMA_F32_PEAK_TF) if r["bound"] == "mfma" else (gb / HBM_PEAK_GBS if gb else None)
         row = {"kernel": name, "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 4), "bound": r["bound"],
-               "tflops": round(tf, 3) if tf else None, "gbs": round(gb, 1) if gb else None, "frac": round(frac, 4) if frac else None}
-        if "pipe_s" in r:
-            # how the launches split over the kernel forms, and the fraction of the measured time the matrix pipe would need
-            # at the peak of the instruction each form issues (bf16x3: 6 bf16 products per fp32 product against the bf16 peak;
-            # Winograd: 16/36 of the products against the fp32 peak)
+               "tflops": round(tf, 3) if tf else None, "gbs": round(gb, 1) if gb else None}
+        if r["bound"] == "mfma" and "pipe_s" in r:
+            # executed fraction: matrix-pipe time at the peak of the instruction each launch issues / measured time
+            row["frac"] = round(r["pipe_s"] / sec, 4)
+            row["frac_basis"] = "executed: issued products at the peak of the instruction issued (bf16x3 6x on the 2500 TFLOP/s bf16 MFMA; Winograd 16/36 and direct 1x on the 157.3 TFLOP/s fp32 MFMA)"
             row["launches_by_form"] = {k: r[k] for k in ("bf3", "wino", "direct") if r.get(k)}
-            row["frac_executed"] = round(r["pipe_s"] / sec, 4)
+            row["frac_algorithmic_vs_fp32_peak"] = round(tf / MFMA_F32_PEAK_TF, 4)
+        elif r["bound"] == "mfma":
+            row["frac"] = round(tf / MFMA_F32_PEAK_TF, 4)          # attention: algorithmic flops against the fp32 matrix peak
+        else:
+            row["frac"] = round(gb / HBM_PEAK_GBS, 4) if gb else None
         if name in pmc and pmc[name].get("mfma_busy_frac") is not None:
-            row["mfma_busy_pmc"] = pmc[name]["mfma_busy_frac"]
+            # NOT measured by this run: merged from the committed rocprofv3 PMC pass of an earlier profiling run
+            row["mfma_busy_pmc_from_profile"] = pmc[name]["mfma_busy_frac"]
+            row["pmc_source"] = pmc[name].get("source", pmc_path)
         out.append(row)
     out.sort(key=lambda z: -z["ms_per_step"])
-    out.append({"kernel": "affine_spline3_wrap (Config E sampling, per denoise step; not in the train step)", "launches_per_step": 0,
-                "ms_per_step": round(t_rot, 4), "bound": "fp64 vector", "gbs": round(8.0 * xr.numel() / (t_rot * 1e-3) / 1e9, 1)})
+    out.append({"kernel": "affine_spline3_wrap (Config E sampling, per denoise step" + ("; not in the train step)" if train else "; only with theta)"),
+                "launches_per_step": 0, "ms_per_step": round(t_rot, 4), "bound": "fp64 vector", "gbs": round(8.0 * xr.numel() / (t_rot * 1e-3) / 1e9, 1)})
     return out, rows
 
 
-def conv_layer_times(L, s, dev, B, ci, co, S, reps=5):
+def conv_layer_times(L, s, dev, B, ci, co, S, reps=5, fwd_only=False):
     """(fwd, dgrad, wgrad) ms of one 3x3 layer through the same dispatch the autograd shells use (ops.py): the
     transformed-weight entry points where the library covers the shape (non-zero workspace: the bf16x3 direct kernel or
     the fp32 Winograd kernels, the library's choice), else the direct kernels.  Also returns the form each pass took
@@ -269,6 +319,9 @@ def conv_layer_times(L, s, dev, B, ci, co, S, reps=5):
         tf = ev_time(lambda: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, s), reps)
     else:
         tf = ev_time(lambda: L.afd_conv_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 3, 0, s), reps)
+    form = lambda n, bit: "direct" if not n else ("bf3" if kinds & bit else "wino")
+    if fwd_only:
+        return tf, 0.0, 0.0, form(nf, 1), None, None
     if ci <= 3:
         td = 0.0
     elif nd:
@@ -276,24 +329,57 @@ def conv_layer_times(L, s, dev, B, ci, co, S, reps=5):
     else:
         td = ev_time(lambda: L.afd_conv_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), B, ci, co, S, S, 3, s), reps)
     tw = ev_time(lambda: L.afd_conv_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, B, ci, co, S, S, 3, 0, ws.data_ptr(), s), reps)
-    form = lambda n, bit: "direct" if not n else ("bf3" if kinds & bit else "wino")
     return tf, td, tw, form(nf, 1), form(nd, 2), ("direct", "wino", "bf3", "direct")[L.afd_conv_wgrad_form(B, ci, co, S, S, 3)]
 
 
-def pmc_traffic(family, launches):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/pmc_families.json,
-    produced by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as the guide's
-    gfx950 correction prescribes).  None when the family has no committed pass."""
-    path = os.path.join(ROOT, "profiles", "pmc_families.json")
+def pmc_traffic(family, launches, path="profiles/pmc_families.json"):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/pmc_families.json for the
+    train step, profiles/pmc_sample_families.json for the sampling forward; produced by tools/pmc_summary.py from separate
+    FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as the guide's gfx950 correction prescribes).  None when the family
+    has no committed pass."""
     try:
-        d = json.load(open(path))[family]
-        return int(d["hbm_bytes_per_step"] / max(1, launches)), d.get("source", "profiles/pmc_families.json")
+        d = json.load(open(os.path.join(ROOT, path)))[family]
+        return int(d["hbm_bytes_per_step"] / max(1, launches)), d.get("source", path)
     except Exception:
         return None, None
 
 
-def _cpu_train_leg(variant, c, B, steps):
-    """The CPU oracle's train step (fwd + autograd bwd + AdamW) on the host cores: (images/s, s/step)."""
+def roofline_of(table, rows, pmc_path="profiles/pmc_families.json"):
+    """The `roofline` object of the arg-max family of a kernel table (ms per step over ALL timed families)."""
+    trow = table[0]
+    name, r = trow["kernel"], rows[trow["kernel"]]
+    traffic, tsrc = pmc_traffic(name, r["launches"], pmc_path)
+    sec = r["ms"] * 1e-3
+    common = {"kernel": name, "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3),
+              "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2), "traffic": traffic, "traffic_source": tsrc}
+    if r["bound"] == "mfma" and "pipe_s" in r:
+        # 3x3 convolution families: priced against the pipe they execute on.  achieved = the bf16-MFMA-equivalent rate of the
+        # products the launches issue (frac x the bf16 peak; the few Winograd / direct launches of the family are converted at
+        # their own instruction's peak, so frac is exactly matrix-pipe-time-at-peak / measured time)
+        frac = r["pipe_s"] / sec
+        ach_alg = r["flops"] / sec / 1e12
+        return dict(common, bound="mfma", achieved=round(frac * MFMA_BF16_PEAK_TF, 1), peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=round(frac, 4),
+                    achieved_algorithmic=round(ach_alg, 2), frac_algorithmic_vs_fp32_peak=round(ach_alg / MFMA_F32_PEAK_TF, 4),
+                    launches_by_form=trow.get("launches_by_form"), mfma_busy_pmc_from_profile=trow.get("mfma_busy_pmc_from_profile"),
+                    pmc_source=trow.get("pmc_source"),
+                    basis="executed: the large layers run the direct form on the bf16 MFMA with exact three-piece splits (6 bf16 products per "
+                          "fp32 product, fp32-class results), the small maps fp32 Winograd (16/36 of the products); achieved = issued products "
+                          "priced at the peak of the instruction that issues them, expressed on the bf16 scale; achieved_algorithmic = "
+                          "direct-form fp32 flops (2*9*Cin*Cout per output pixel, SURVEY 8d) / HIP-event time")
+    if r["bound"] == "mfma":
+        ach = r["flops"] / sec / 1e12
+        return dict(common, bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TF, 4),
+                    mfma_busy_pmc_from_profile=trow.get("mfma_busy_pmc_from_profile"), pmc_source=trow.get("pmc_source"),
+                    basis="algorithmic attention flops (4*L*L*C forward, 2.5x that backward, SURVEY 8d) / HIP-event time; fp32 results; the "
+                          "d-contractions run as 3-piece bf16 splits on the matrix cores (fp32-exact), the rank-d updates and the softmax on the "
+                          "vector pipe; priced against the fp32 matrix peak")
+    ach = r["bytes"] / sec / 1e9
+    return dict(common, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
+
+
+def _cpu_train_leg(variant, c, B, steps, warm=1):
+    """The CPU oracle's train step (fwd + autograd bwd + AdamW) on the host cores: (images/s, s/step) over `steps` timed steps
+    after `warm` untimed ones."""
     import contextlib, io
     import afdm
     from oracle import ref_ops as R
@@ -307,7 +393,7 @@ def _cpu_train_leg(variant, c, B, steps):
     g = torch.Generator().manual_seed(42)
     images = torch.rand(B, c, 32, 32, generator=g) * 2 - 1
     times = []
-    for it in range(steps + 1):
+    for it in range(steps + warm):
         t0 = time.perf_counter()
         t = torch.randint(1, 1000, (B,))
         eps = torch.randn(images.shape)
@@ -317,7 +403,7 @@ def _cpu_train_leg(variant, c, B, steps):
                 p, m[kname], v2[kname] = R.adamw_step(sd[kname], grads[kname], m[kname], v2[kname], it + 1, 3e-4)
                 sd[kname].copy_(p)
         times.append(time.perf_counter() - t0)
-    dt = sum(times[1:]) / steps
+    dt = sum(times[warm:]) / steps
     return B / dt, dt
 
 
@@ -344,22 +430,34 @@ def _cpu_sample_leg(n, steps):
     return n / (per * 999), per
 
 
-def cpu_baseline(variant=3):
+def cpu_baseline(variant=3, batch=256):
     """The CPU oracle (oracle/ref_ops.py, torch-CPU fp32: the reference's own ATen path restated) on the GPU box's host
-    cores, bounded samples of the same workloads (~25 s of CPU work in all): `value` is the train step of the benched
-    variant at B=64 (instead of 256), `legs` adds BASELINE config 1 (variant 0, 1 channel, B=16) and the sampling loop."""
+    cores, bounded samples of the same workloads (~60 s of CPU work in all): `value` is ONE train step of the benched
+    configuration at the benched batch size (B=256: the size the GPU number is quoted on; one timed step after a B=16
+    warm-up of the same graph), `legs` adds the same variant at B=64, BASELINE config 2 (variant 1, Config B) at B=64,
+    BASELINE config 1 (variant 0, 1 channel, B=16) and the sampling loop (configs 1-3)."""
     torch.set_num_threads(host_threads())
     cores = torch.get_num_threads()
-    v, dt = _cpu_train_leg(variant, 3, 64, 3)
-    legs = [{"config": f"variant {variant} train step, 3x32x32, B=64", "value": round(v, 2), "unit": "images/s", "s_per_step": round(dt, 3)}]
+    _cpu_train_leg(variant, 3, 16, 1)                                    # warm the allocator / thread pool
+    vB, dtB = _cpu_train_leg(variant, 3, batch, 1, warm=0)
+    legs = [{"config": f"variant {variant} (Config {'ABCDE'[variant]}) train step, 3x32x32, B={batch}: 1 timed step", "value": round(vB, 2), "unit": "images/s",
+             "s_per_step": round(dtB, 3)}]
+    v, dt = _cpu_train_leg(variant, 3, 64, 2)
+    legs.append({"config": f"variant {variant} train step, 3x32x32, B=64: 2 timed steps after 1 warm-up", "value": round(v, 2), "unit": "images/s",
+                 "s_per_step": round(dt, 3)})
+    if variant != 1:
+        vb, dtb = _cpu_train_leg(1, 3, 64, 2)
+        legs.append({"config": "BASELINE config 2: variant 1 (Config B, filtered resampling only), 3x32x32, B=64 train step (Train.ipynb:106)",
+                     "value": round(vb, 2), "unit": "images/s", "s_per_step": round(dtb, 3)})
     v1, dt1 = _cpu_train_leg(0, 1, 16, 3)
     legs.append({"config": "BASELINE config 1: variant 0 (Config A), MNIST-shaped 1x32x32, B=16 train step", "value": round(v1, 2),
                  "unit": "images/s", "s_per_step": round(dt1, 3)})
     vs, per = _cpu_sample_leg(16, 10)
     legs.append({"config": "Config D sample, n=16: 10 timed denoise steps x 99.9 -> one 999-step trajectory", "value": round(vs, 4),
                  "unit": "images/s", "s_per_denoise_step": round(per, 3)})
-    return {"value": round(v, 2), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"CPU oracle (oracle/ref_ops.py, torch-CPU fp32) train step, variant {variant}, B=64, 3 timed steps after 1 warm-up, {dt:.2f} s/step",
+    return {"value": round(vB, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle (oracle/ref_ops.py, torch-CPU fp32) train step, variant {variant}, B={batch} (the benched size), 1 timed step after a "
+                      f"B=16 warm-up, {dtB:.2f} s/step",
             "legs": legs}
 
 
@@ -508,40 +606,21 @@ def main():
                                                       "n_per_gpu": NS * n, "streams": NS, "seconds": round(cdt, 3)}
 
     if rank == 0 and world == 1:
-        if not args.no_kernels and args.variant == 3:       # (the family table is written over Config D's layer shapes)
-            log("per-kernel timing")
-            table, rows = kernel_table(dev, args.batch)
-            trow = table[0]                              # arg-max of ms/step over ALL timed families
-            name, r = trow["kernel"], rows[table[0]["kernel"]]
-            traffic, tsrc = pmc_traffic(name, r["launches"])
-            sec = r["ms"] * 1e-3
-            if r["bound"] == "mfma":
-                ach = r["flops"] / sec / 1e12
-                basis = ("algorithmic direct-form flops (2*9*Cin*Cout per output pixel, SURVEY 8d) / HIP-event time, priced against the fp32 matrix "
-                         "peak (the results are fp32); the large layers run on the bf16 MFMA with exact three-piece splits (6 bf16 products per "
-                         "fp32 product), the small maps on fp32 Winograd kernels (16/36 of the products), so frac is not bounded by 1: "
-                         "frac_executed prices each launch's issued products against the peak of ITS instruction (bf16 2500 / fp32 157.3 TFLOP/s)"
-                         + ("; weight-gradient launches are sized to run on a second stream beside the backward chain, so timed alone, as here, they "
-                            "do not fill the chip" if name == "conv3x3_wgrad" else "")) if name.startswith("conv") else \
-                        ("algorithmic attention flops (4*L*L*C forward, 2.5x that backward, SURVEY 8d) / HIP-event time; fp32 results; head dim 8: "
-                         "d-contractions as 3-piece bf16 splits on the matrix cores (fp32-exact), rank-8 updates and softmax on the vector pipe; "
-                         "priced against the fp32 matrix peak")
-                result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                      "frac": round(ach / MFMA_F32_PEAK_TF, 4), "frac_executed": trow.get("frac_executed"),
-                                      "launches_by_form": trow.get("launches_by_form"), "peak_bf16": MFMA_BF16_PEAK_TF,
-                                      "mfma_busy_pmc": trow.get("mfma_busy_pmc"), "traffic": traffic,
-                                      "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3),
-                                      "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2), "basis": basis, "traffic_source": tsrc}
-            else:
-                ach = r["bytes"] / sec / 1e9
-                result["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                                      "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3),
-                                      "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2), "traffic_source": tsrc}
+        if not args.no_kernels and args.variant == 3:       # (the family tables are written over Config D's layer shapes)
+            log("per-kernel timing: train step")
+            table, rows = kernel_table(dev, args.batch, "train")
+            result["roofline"] = roofline_of(table, rows)
             result["kernels"] = table
+            if "sample" in result:
+                log("per-kernel timing: sampling forward")
+                stable, srows = kernel_table(dev, args.sample_n, "sample")
+                result["sample"]["roofline"] = roofline_of(stable, srows, "profiles/pmc_sample_families.json")
+                result["sample"]["kernels"] = stable
+                result["sample"]["kernel_ms_sum_per_denoise_step"] = round(sum(r["ms"] for r in srows.values()), 4)
+                result["sample"]["ms_per_denoise_step"] = round(result["sample"]["seconds"] * 1e3 / result["sample"]["denoise_steps"], 4)
         if not args.no_cpu_baseline:
             log(f"CPU baseline on {host_threads()} host threads")
-            result["cpu_baseline"] = cpu_baseline(args.variant)
+            result["cpu_baseline"] = cpu_baseline(args.variant, args.batch)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -100,12 +100,12 @@ def train_cuda(args, rank, world, dev):
     sl = slice(rank * B, (rank + 1) * B)
     T = lambda a: torch.from_numpy(np.asarray(a))
     loss = step(T(g["images"][sl]).to(dev), t=T(g["t0"][sl]), eps=T(g["eps0"][sl]).to(dev))
-    overlapped = step.ddp.overlapped_last_step
+    overlapped, started = step.ddp.overlapped_last_step, step.ddp.started_before_finish
     lt = loss.detach().cpu().reshape(1)
     dist.all_reduce(lt)
     if rank == 0:
         flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
-        torch.save({"loss_mean": (lt / world).item(), "params": flat, "overlapped_buckets": overlapped,
+        torch.save({"loss_mean": (lt / world).item(), "params": flat, "overlapped_buckets": overlapped, "started_before_finish": started,
                     "n_buckets": len(step.ddp.slices), "slices": torch.tensor(step.ddp.slices)}, args.out)
 
 

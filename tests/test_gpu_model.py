@@ -191,14 +191,34 @@ def test_train_step_vs_reference(A, variant, conv_path):
     # amplifies a 1e-9 absolute gradient difference into percents (zero-initialised biases with |g| ~ 1e-7: even the CPU
     # oracle, the same ATen ops in another graph, is 8e-5 off the reference on variant 0's bot2 bias), so the 1e-4 gate
     # is taken over the elements with |g_ref| >= 1e-6 and the whole tensor is gated at 2e-3.
-    e_par, e_par_all = 0.0, 0.0
+    e_par, e_par_all, over = 0.0, 0.0, {}
     for k in g.files:
         if k.startswith("param1."):
             got, want, gref = params[k[7:]].detach().cpu().numpy(), g[k], np.abs(g["grad0." + k[7:]])
             m = gref >= 1e-6
             assert m.mean() > 0.9, k
             e_par = max(e_par, rel_l2(got[m], want[m]))
-            e_par_all = max(e_par_all, rel_l2(got, want))
+            e_all = rel_l2(got, want)
+            e_par_all = max(e_par_all, e_all)
+            if e_all > 1e-4:
+                over[k[7:]] = e_all
+    if over:
+        # the evidence for the relaxed whole-tensor gate: the CPU oracle (the same ATen ops in another autograd graph) takes the
+        # same step from the same initial parameters; its own whole-tensor error against the reference on exactly these tensors
+        from oracle import ref_ops as R
+        afdm.set_seed(42)
+        ref_net = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET) if variant else None, device="cpu", variant=variant)
+        sd = {k: v.clone().requires_grad_(True) for k, v in ref_net.state_dict().items()}
+        _, _, ah = R.noise_schedule(1000)
+        _, _, og = R.train_step_loss_and_grads(sd, T(g["images"]), T(g["t0"]), T(g["eps0"]), variant, F_SET, ah)
+        for k, e_hip in sorted(over.items(), key=lambda kv: -kv[1]):
+            with torch.no_grad():
+                p1, _, _ = R.adamw_step(sd[k].detach(), og[k], torch.zeros_like(og[k]), torch.zeros_like(og[k]), 1, 3e-4)
+            e_orc = rel_l2(p1, g["param1." + k])
+            small = float((np.abs(g["grad0." + k]) < 1e-6).mean())
+            print(f"  post-AdamW whole tensor > 1e-4: {k}: HIP {e_hip:.2e}, CPU oracle {e_orc:.2e} vs the reference; "
+                  f"{100 * small:.1f} % of its elements have |g_ref| < 1e-6, max |g_ref| {np.abs(g['grad0.' + k]).max():.2e}")
+            note("train step: post-AdamW whole-tensor error of the CPU ORACLE on the tensors where HIP exceeds 1e-4", e_orc, (variant, k))
     l1 = step(images, t=T(g["t1"]), eps=T(g["eps1"]).to(dev))
     e_loss1 = abs(l1.item() - g["losses"][1]) / abs(g["losses"][1])
     print(f"train step v{variant} [{conv_path}]: loss0 rel {e_loss0:.2e}, worst grad rel-L2 {e_grad:.2e}, worst grad-norm rel {e_norm:.2e}, "
@@ -273,6 +293,42 @@ def test_full_batch_step_bf16x3_kernels_agree_with_fp32_kernels(A):
             worst = max(worst, ((a - b).norm() / b.norm()).item())
             check("full-batch step: bf16x3 vs fp32 kernels, parameter gradients", outs[0][1][n].cpu(), outs[1][1][n].cpu(), 1e-5, n)
     assert worst < 1e-5
+
+
+def test_full_batch_step_vs_cpu_oracle(A):
+    """BASELINE size against the ORACLE (not HIP vs HIP): Config D, B = 256, one forward + backward
+    (ddpm_utils.py:489,498-509) on the HIP engine with the kernels the rule picks at this size, against
+    oracle.ref_ops.train_step_loss_and_grads on the box's host cores with the same images / t / eps:
+    loss <= 2e-5, EVERY parameter-gradient tensor <= 1e-4, recorded in the ledger."""
+    afdm, dev = A
+    from afdm import ops
+    from oracle import ref_ops as R
+    afdm.set_seed(42)
+    model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device="cpu", variant=3)
+    sd = {k: v.clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    diff = afdm.Diffusion(noise_steps=1000, img_size=32, device=dev)
+    g = torch.Generator().manual_seed(23)
+    images = torch.rand(256, 3, 32, 32, generator=g) * 2 - 1
+    t = torch.randint(1, 1000, (256,), generator=g)
+    eps = torch.randn(256, 3, 32, 32, generator=g)
+    step = afdm.TrainStep(model, diff, lr=3e-4, graph=False)
+    loss = step._fwd_bwd(images.to(dev), t.to(dev), eps.to(dev))           # forward + backward of the product step, no AdamW
+    torch.cuda.synchronize()
+    got = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
+    _, _, ah = R.noise_schedule(1000)
+    nt = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    try:
+        loss_o, _, grads_o = R.train_step_loss_and_grads(sd, images, t, eps, 3, F_SET, ah)
+    finally:
+        torch.set_num_threads(nt)
+    e_loss = abs(loss.item() - loss_o.item()) / abs(loss_o.item())
+    note("full-batch (B=256) step vs CPU oracle: loss", e_loss)
+    assert e_loss < 2e-5, e_loss
+    assert set(grads_o) == set(got) and len(got) == 182
+    worst = max(check("full-batch (B=256) step vs CPU oracle: parameter gradients (fp32 vs fp32)", got[k], grads_o[k], 1e-4, k) for k in got)
+    print(f"B=256 Config-D step vs CPU oracle: loss rel {e_loss:.2e}, worst parameter-gradient rel-L2 {worst:.2e} over {len(got)} tensors")
 
 
 def test_graph_replay_equals_eager(A):
@@ -361,7 +417,8 @@ def test_sample_100_steps_vs_reference(A, variant, c, conv_path):
     rv = diff.revert(model, n=2, image_channels=c, noise_source="cpu")
     d = rv.cpu().numpy().astype(int) - g[f"{tag}.revert"].astype(int)
     assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.01
-    if variant == 3:   # Config E: per-step rotation (CPU scipy, like the reference)
+    if variant == 3:   # Config E: per-step rotation (device spline rotate, bit-identical to scipy's on the golden angles); uint8 gate:
+        #                  99 rotations by 90/100 degrees amplify rounding-boundary flips, so <= 2 grey levels on < 2 % of the pixels
         afdm.set_seed(7)
         xr, _ = diff.sample(model, n=2, image_channels=c, theta=90.0, noise_source="cpu")
         d = xr.cpu().numpy().astype(int) - g[f"{tag}.sample_theta90_x"].astype(int)
@@ -546,7 +603,10 @@ def _single_rank_step(afdm, dev):
 
 def test_two_rank_data_parallel_equals_single_rank(A, tmp_path):
     """2 processes on the one GPU (gloo, buckets staged through the host): B=2+2 must equal one rank with B=4, and the
-    bucket all-reduces must have started DURING backward (all but the first-layers bucket, which completes with it)."""
+    bucket all-reduces must have started DURING backward: counted when autograd's backward returns, BEFORE the final flush
+    of the weight-gradient queue -- three of the four (the first-layers bucket, the smallest, completes with backward
+    itself and starts at that flush).  The six stages' time-embedding gradients leave through per-stage nodes, so they do
+    not hold the decoder buckets back."""
     afdm, dev = A
     got = _run_ranks(tmp_path, "train", 29533, "ddp.pt")
     loss, flat = _single_rank_step(afdm, dev)
@@ -554,7 +614,9 @@ def test_two_rank_data_parallel_equals_single_rank(A, tmp_path):
           "buckets", got["slices"].tolist(), "started before the end of backward:", got["overlapped_buckets"])
     assert abs(got["loss_mean"] - loss) < 1e-5 * abs(loss)
     assert rel_l2(got["params"], flat) < 1e-6
-    assert got["n_buckets"] == 4 and got["overlapped_buckets"] == 4
+    assert got["n_buckets"] == 4 and got["overlapped_buckets"] == 3 and got["started_before_finish"] == 4
+    sizes = [b - a for a, b in got["slices"].tolist()]
+    assert sizes[0] == min(sizes)                           # the bucket that cannot overlap is the smallest (inc .. sa2)
 
 
 def test_two_rank_data_parallel_graph_mode(A, tmp_path):
@@ -575,7 +637,7 @@ def test_two_rank_rccl_data_parallel(A, tmp_path):
     got = _run_ranks(tmp_path, "train", 29535, "ddp_rccl.pt", backend="nccl")
     loss, flat = _single_rank_step(afdm, dev)
     assert abs(got["loss_mean"] - loss) < 1e-5 * abs(loss) and rel_l2(got["params"], flat) < 1e-6
-    assert got["overlapped_buckets"] == 4
+    assert got["overlapped_buckets"] == 3 and got["started_before_finish"] == 4
 
 
 def test_two_rank_sharded_sampling_equals_single_rank(A, tmp_path):
@@ -598,3 +660,26 @@ def test_two_rank_sharded_sampling_equals_single_rank(A, tmp_path):
     afdm.set_seed(5)
     x1, r1 = diff.sample_sharded(model, n=5, image_channels=3)
     assert torch.equal(x1, xq) and torch.equal(r1, rq)
+
+
+def test_bench_entry_point_two_ranks_dry_run(A, tmp_path):
+    """The driver's multi-GPU command line, rehearsed: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`
+    with both ranks on the one GPU over gloo (AFD_DIST_BACKEND).  One JSON line from rank 0 with the whole-job fields right.
+    (No hardware scaling number comes out of this: two ranks share one card.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0", AFD_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--no-sample", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, timeout=900, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
+    assert math.isfinite(d["final_loss"]) and d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+    assert d["metric"] == "train_step_images_per_sec" and d["unit"] == "images/s" and d["vs_baseline"] is None
