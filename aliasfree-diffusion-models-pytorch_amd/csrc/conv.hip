@@ -780,12 +780,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce4(const float* __restrict__ p
   }
 }
 
-static void launch_wgrad_reduce(const float* part, float* dw, long n, int slabs, const float* bp, float* db, int nb, int accumulate,
-                                int T, hipStream_t s) {
-  if (n % 128 == 0 && (n / T) % 4 == 0)
-    hipLaunchKernelGGL(wgrad_reduce4, dim3((unsigned)(n / 128 + (nb + 31) / 32)), dim3(256), 0, s, part, dw, n, slabs, bp, db, nb, accumulate, T);
-  else
-    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((n + nb + 31) / 32)), dim3(256), 0, s, part, dw, n, slabs, bp, db, nb, accumulate, T);
+int fold_launch(const afd_fold_desc* descs, int n, hipStream_t s);          // fold.hip
+
+// The deterministic fold of weight-gradient slabs (and bias slabs) = one or two fold descriptors (fold.hip).  With `out`
+// the descriptors are handed to the caller (who batches them with other layers' folds into one launch, later, on the
+// same stream); without, they are folded now -- through the same kernel, so both ways give the same bits.
+struct FoldSink { afd_fold_desc* out; int n; };
+static int launch_wgrad_reduce(const float* part, float* dw, long n, int slabs, const float* bp, float* db, int nb, int accumulate,
+                               int T, hipStream_t s, FoldSink* sink) {
+  afd_fold_desc d[2];
+  int nd = 0;
+  d[nd++] = afd_fold_desc{part, dw, n, n, n / T, (long)T, slabs, accumulate};
+  if (nb > 0) d[nd++] = afd_fold_desc{bp, db, (long)nb, (long)nb, (long)nb, 1L, slabs, accumulate};
+  if (sink) {
+    for (int i = 0; i < nd; ++i) sink->out[sink->n++] = d[i];
+    return AFD_OK;
+  }
+  return fold_launch(d, nd, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1057,13 +1068,13 @@ int afd_conv_wgrad_form(int B, int Cin, int Cout, int H, int W, int ksize) {
   return wgrad_wino_plan(B, Cin, Cout, H, W, &a, &b, &c, &d) ? 1 : 0;
 }
 
-int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
-                   int ksize, int accumulate, void* workspace, afd_stream_t st) {
-  AFD_REQUIRE(x && dy && dw && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "afd_conv_wgrad: bad argument");
-  AFD_REQUIRE(ksize == 1 || ksize == 3, "afd_conv_wgrad: ksize %d not in {1,3}", ksize);
-  hipStream_t s = as_stream(st);
+static int conv_wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
+                           int ksize, int accumulate, void* workspace, FoldSink* sink, hipStream_t s, const char* who) {
+  AFD_REQUIRE(x && dy && dw && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad argument", who);
+  AFD_REQUIRE(ksize == 1 || ksize == 3, "%s: ksize %d not in {1,3}", who, ksize);
   const int T = ksize * ksize;
   const TileGeom g = make_geom(H, W, 64, ksize == 3 ? 1 : 0);
+  int rc = AFD_OK;
   if (ksize == 3 && !dbias && workspace) {                               // bf16x3 form on the matrix pipe, else Winograd F(3x3, 2x2): 16 multiplies per tile instead of 36
     float* part = static_cast<float*>(workspace);
     int slabs = wgrad_bf3(x, dy, part, B, Cin, Cout, H, W, s);
@@ -1071,8 +1082,8 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
     if (!slabs) slabs = wgrad_wino(x, dy, part, B, Cin, Cout, H, W, s);
     if (slabs) {
       const long n = (long)Cout * Cin * 9;
-      launch_wgrad_reduce(part, dw, n, slabs, nullptr, nullptr, 0, accumulate, 9, s);
-      return check_launch("afd_conv_wgrad");
+      rc = launch_wgrad_reduce(part, dw, n, slabs, nullptr, nullptr, 0, accumulate, 9, s, sink);
+      return rc != AFD_OK ? rc : check_launch(who);
     }
   }
   if (ksize == 1 && workspace) {                                         // bf16x3 form straight from global memory (HBM-bound)
@@ -1083,12 +1094,12 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
       const long n = (long)Cout * Cin;
       float* bp = dbias ? part + (size_t)slabs * n : nullptr;
       pw_wgrad_bf3(x, dy, part, bp, B, Cin, Cout, H * W, s);
-      launch_wgrad_reduce(part, dw, n, slabs, bp, dbias, dbias ? Cout : 0, accumulate, 1, s);
-      return check_launch("afd_conv_wgrad");
+      rc = launch_wgrad_reduce(part, dw, n, slabs, bp, dbias, dbias ? Cout : 0, accumulate, 1, s, sink);
+      return rc != AFD_OK ? rc : check_launch(who);
     }
   }
   if (tile_ok(H, W, 64) && g.XS <= 256 && (long)B * H * W * (Cin > Cout ? Cin : Cout) < (1L << 31)) {
-    AFD_REQUIRE(workspace, "afd_conv_wgrad: workspace is NULL");
+    AFD_REQUIRE(workspace, "%s: workspace is NULL", who);
     const WgradPlan p = wgrad_plan(B, Cin, Cout, H, W, ksize);
     float* part = static_cast<float*>(workspace);
     const long n = (long)Cout * Cin * T;
@@ -1097,21 +1108,35 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int
     else if (p.npb == 4) launch_wgrad_roles<9, 4>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
     else if (p.npb == 5) launch_wgrad_roles<9, 5>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
     else launch_wgrad_roles<9, 8>(x, dy, part, bp, B, Cin, Cout, H, W, p, g, s);
-    launch_wgrad_reduce(part, dw, n, p.slabs, bp, dbias, dbias ? Cout : 0, accumulate, T, s);
-    return check_launch("afd_conv_wgrad");
+    rc = launch_wgrad_reduce(part, dw, n, p.slabs, bp, dbias, dbias ? Cout : 0, accumulate, T, s, sink);
+    return rc != AFD_OK ? rc : check_launch(who);
   } else {
     const dim3 grid((unsigned)(Cout * Cin));
     if (ksize == 3) hipLaunchKernelGGL(conv_direct_wgrad<3>, grid, dim3(256), 0, s, x, dy, dw, B, Cin, Cout, H, W, accumulate);
     else hipLaunchKernelGGL(conv_direct_wgrad<1>, grid, dim3(256), 0, s, x, dy, dw, B, Cin, Cout, H, W, accumulate);
   }
   if (dbias) {                                                            // direct path only: plane sums + column sum
-    AFD_REQUIRE(workspace, "afd_conv_wgrad: workspace is NULL");
+    AFD_REQUIRE(workspace, "%s: workspace is NULL", who);
     float* bp = static_cast<float*>(workspace);
     const long planes = (long)B * Cout;
     hipLaunchKernelGGL(conv_dbias_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, dy, bp, planes, H * W);
     hipLaunchKernelGGL(conv_dbias_final, dim3((Cout + 31) / 32), dim3(256), 0, s, bp, dbias, B, Cout, accumulate);
   }
-  return check_launch("afd_conv_wgrad");
+  return check_launch(who);
+}
+
+int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
+                   int ksize, int accumulate, void* workspace, afd_stream_t st) {
+  return conv_wgrad_impl(x, dy, dw, dbias, B, Cin, Cout, H, W, ksize, accumulate, workspace, nullptr, as_stream(st), "afd_conv_wgrad");
+}
+
+int afd_conv_wgrad_partials(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
+                            int ksize, int accumulate, void* workspace, afd_fold_desc* folds_out, int* n_folds, afd_stream_t st) {
+  AFD_REQUIRE(folds_out && n_folds, "afd_conv_wgrad_partials: folds_out / n_folds are NULL");
+  FoldSink sink{folds_out, 0};
+  const int rc = conv_wgrad_impl(x, dy, dw, dbias, B, Cin, Cout, H, W, ksize, accumulate, workspace, &sink, as_stream(st), "afd_conv_wgrad_partials");
+  *n_folds = sink.n;
+  return rc;
 }
 
 }  // extern "C"

@@ -189,12 +189,33 @@ __global__ void silu_linear_fwd_batched_k(const float* __restrict__ temb, SiluBa
   if (lane == 0) d.out[i][(long)b * d.N[i] + n] = s + (d.bias[i] ? d.bias[i][n] : 0.f);
 }
 // dw[n,k] = sum_b dout[b,n] silu(temb[b,k]).  Block = one output row n x 32 columns k x 8 batch groups;
-// the 8 partial sums meet in LDS (fixed order).
+// the 8 partial sums meet in LDS (fixed order).  Row blockIdx.y == N (present when db != NULL) holds the bias gradient
+// db[n] = sum_b dout[b,n] instead: 32 outputs n per block, the same 8 batch groups -- one launch for both.
 __global__ __launch_bounds__(256) void silu_linear_dw_k(const float* __restrict__ temb, const float* __restrict__ dout, float* __restrict__ dw,
-                                                        int B, int K, int N, int accumulate) {
+                                                        float* __restrict__ db, int B, int K, int N, int accumulate) {
   __shared__ float red[8][33];
+  const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
+  if ((int)blockIdx.y == N) {
+    const int n = blockIdx.x * 32 + l;
+    if (blockIdx.x * 32 >= N) return;
+    float s0 = 0.f, s1 = 0.f;
+    if (n < N) {
+      int b = g;
+      for (; b + 8 < B; b += 16) { s0 += dout[(long)b * N + n]; s1 += dout[(long)(b + 8) * N + n]; }
+      if (b < B) s0 += dout[(long)b * N + n];
+    }
+    red[g][l] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && n < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t += red[j][l];
+      db[n] = accumulate ? db[n] + t : t;
+    }
+    return;
+  }
   const int n = blockIdx.y;
-  const int k = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + l;
   float s0 = 0.f, s1 = 0.f;
   if (k < K) {
     int b = g;
@@ -204,28 +225,15 @@ __global__ __launch_bounds__(256) void silu_linear_dw_k(const float* __restrict_
     }
     if (b < B) s0 += dout[(long)b * N + n] * silu(temb[(long)b * K + k]);
   }
-  red[g][threadIdx.x & 31] = s0 + s1;
+  red[g][l] = s0 + s1;
   __syncthreads();
   if (g == 0 && k < K) {
     float t = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t += red[j][threadIdx.x & 31];
+    for (int j = 0; j < 8; ++j) t += red[j][l];
     float* o = dw + (long)n * K + k;
     *o = accumulate ? *o + t : t;
   }
-}
-__global__ void silu_linear_db_k(const float* __restrict__ dout, float* __restrict__ db, int B, int N, int accumulate) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 4 <= B; b += 4) {
-    s0 += dout[(long)b * N + n]; s1 += dout[(long)(b + 1) * N + n];
-    s2 += dout[(long)(b + 2) * N + n]; s3 += dout[(long)(b + 3) * N + n];
-  }
-  for (; b < B; ++b) s0 += dout[(long)b * N + n];
-  const float s = (s0 + s1) + (s2 + s3);
-  db[n] = accumulate ? db[n] + s : s;
 }
 // dtemb[b,k] += silu'(temb[b,k]) * sum_n dout[b,n] w[n,k]
 __global__ void silu_linear_dx_k(const float* __restrict__ temb, const float* __restrict__ w, const float* __restrict__ dout,
@@ -397,8 +405,8 @@ int afd_silu_linear_bwd(const float* temb, const float* w, const float* dout, fl
                         int B, int K, int N, int accumulate, afd_stream_t st) {
   AFD_REQUIRE(temb && w && dout && dw && B > 0 && K > 0 && N > 0, "afd_silu_linear_bwd: bad argument");
   hipStream_t s = as_stream(st);
-  hipLaunchKernelGGL(silu_linear_dw_k, dim3((K + 31) / 32, N), dim3(256), 0, s, temb, dout, dw, B, K, N, accumulate);
-  if (dbias) hipLaunchKernelGGL(silu_linear_db_k, dim3((N + 255) / 256), dim3(256), 0, s, dout, dbias, B, N, accumulate);
+  AFD_REQUIRE(!dbias || (N + 31) / 32 <= (K + 31) / 32, "afd_silu_linear_bwd: N > K is not covered");   // (the bias row rides in the dW grid)
+  hipLaunchKernelGGL(silu_linear_dw_k, dim3((K + 31) / 32, dbias ? N + 1 : N), dim3(256), 0, s, temb, dout, dw, dbias, B, K, N, accumulate);
   if (dtemb) hipLaunchKernelGGL(silu_linear_dx_k, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, s, temb, w, dout, dtemb, B, K, N);
   return check_launch("afd_silu_linear_bwd");
 }

@@ -530,6 +530,13 @@ int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int
 
 int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, int accumulate, afd_stream_t st);
 
+int afd_layernorm_c_bwd_partials(const float* x, const float* dy, const float* stats, int B, int C, int HW, float* part, afd_stream_t st) {
+  AFD_REQUIRE(x && dy && stats && part && B > 0 && C > 0 && HW > 0, "afd_layernorm_c_bwd_partials: bad argument");
+  const long planes = (long)B * C;
+  hipLaunchKernelGGL(ln_c_bwd_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, as_stream(st), x, dy, stats, C, HW, planes, part);
+  return check_launch("afd_layernorm_c_bwd_partials");
+}
+
 int afd_layernorm_c_bwd_params(const float* x, const float* dy, const float* stats, int B, int C, int HW,
                                float* part, float* dgamma, float* dbeta, int accumulate, afd_stream_t st) {
   AFD_REQUIRE(x && dy && stats && part && dgamma && dbeta && B > 0 && C > 0 && HW > 0, "afd_layernorm_c_bwd_params: bad argument");

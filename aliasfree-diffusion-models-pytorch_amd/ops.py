@@ -186,11 +186,16 @@ class _GradMode:
     sides = []            # all side streams: queued launches are dealt to them in turn (one in-order stream runs ONE
     #                       weight-gradient kernel at a time; two let a layer's slab reduce overlap the next layer's multiplies)
     turn = 0
-    pending = []          # (launch closure, tensors it reads): parameter-gradient kernels not launched yet
-    launched = []         # the same pairs after launch, held until the join (their buffers are in use on the side stream)
+    pending = []          # (launch closure, tensors it reads, params): parameter-gradient kernels not launched yet
+    launched = []         # the same triples after launch, held until the join (their buffers are in use on the side stream)
     batch = 8             # fork the side stream once per this many layers (few cross-stream edges in a captured graph)
     on_write = None       # callable(list of Parameters): their .grad is complete as far as ENQUEUED work goes -- the
     #                       data-parallel exchange's readiness hook (training.GradAllReduce.wrote)
+    fold_hint = None      # callable(list of Parameters) -> bool: would reporting these complete a data-parallel bucket?
+    folds = []            # per side stream: [packed afd_fold_desc bytes, ...] of producers already launched there
+    fold_writes = []      # params whose .grad is complete once the queued folds have been launched
+    flushes = 0           # flushes since the last fold launch
+    fold_every = 4        # launch the queued folds every this many flushes (and at the join, and when a bucket completes)
 
 
 def _wrote(*params):
@@ -200,60 +205,102 @@ def _wrote(*params):
         cb([q for q in params if q is not None])
 
 
+FOLD_DESC = "<QQqqqqii"      # afd_fold_desc: part, dst, n, stride, inner, rstride, splits, accumulate (56 bytes)
+
+
+def fold_desc(part_ptr, dst_ptr, n, splits, stride=None, inner=None, rstride=1, accumulate=1):
+    import struct
+    return struct.pack(FOLD_DESC, part_ptr, dst_ptr, n, n if stride is None else stride, n if inner is None else inner, rstride,
+                       splits, accumulate)
+
+
+def fold_now(descs, stream=None):
+    """One afd_fold_batched launch for packed descriptors (bytes)."""
+    import ctypes
+    buf = ctypes.create_string_buffer(descs, len(descs))
+    lib().afd_fold_batched(ctypes.addressof(buf), len(descs) // 56, _stream() if stream is None else stream)
+
+
 def defer_to_side_stream(fn, *keep, writes=()):
     """Queue fn(stream_handle) -- a launch whose result nothing downstream of backward consumes (a parameter gradient) --
     for the side stream.  `keep`: the tensors it reads; they are held until the join, so autograd cannot add into them
     in place and the allocator cannot recycle them while the side stream still reads them.  `writes`: the Parameters
-    whose .grad the launch completes (reported to `on_write` once it is launched)."""
+    whose .grad the launch completes (reported to `on_write` once it is launched).
+    fn may RETURN packed afd_fold_desc bytes: the deterministic fold that finishes its gradient.  Those are not launched
+    per layer: they queue up on the producer's stream and ONE afd_fold_batched launch folds every `fold_every` flushes'
+    worth of them (csrc/fold.hip; `writes` are then reported when that launch is enqueued).  fn = None with
+    keep[0] = descriptor bytes queues a fold whose partials a main-stream kernel has already produced."""
     _GradMode.pending.append((fn, keep, writes))
     if len(_GradMode.pending) >= _GradMode.batch:
         flush_wgrads()
 
 
-def flush_wgrads():
-    """Launch the queued parameter-gradient kernels on the side stream (one fork for the whole batch)."""
-    sides, q = _GradMode.sides, _GradMode.pending
-    if not q:
+def flush_wgrads(final=False):
+    """Launch the queued parameter-gradient kernels on the side stream (one fork for the whole batch), then the queued
+    folds if it is time: every `fold_every` flushes, at the join (final) and whenever they would complete a bucket."""
+    G = _GradMode
+    sides, q = G.sides, G.pending
+    if not q and not (final and any(G.folds)):
         return
     cur = torch.cuda.current_stream()
     lanes = [[] for _ in sides]
     for item in q:
-        lanes[_GradMode.turn % len(sides)].append(item)
-        _GradMode.turn += 1
-    for side, items in zip(sides, lanes):
+        lanes[G.turn % len(sides)].append(item)
+        G.turn += 1
+    if len(G.folds) != len(sides):
+        G.folds = [[] for _ in sides]
+    done = []
+    for k, (side, items) in enumerate(zip(sides, lanes)):
         if not items:
             continue
         side.wait_stream(cur)                                                 # fork: every queued dY (and the zeroed .grad) exists
         with torch.cuda.stream(side):
             h = side.cuda_stream
-            for fn, _, _ in items:
-                fn(h)
-    _GradMode.launched.extend(q)
-    _GradMode.pending = []
-    if _GradMode.on_write is not None:
-        _wrote(*[w for _, _, ws in q for w in ws])
+            for fn, keep, ws in items:
+                descs = fn(h) if fn is not None else keep[0]
+                if descs:
+                    G.folds[k].append(descs)
+                    G.fold_writes.extend(ws)
+                else:
+                    done.extend(ws)
+    G.launched.extend(q)
+    G.pending = []
+    G.flushes += 1
+    if any(G.folds) and (final or G.flushes >= G.fold_every or (G.fold_hint is not None and G.fold_hint(G.fold_writes + done))):
+        for k, side in enumerate(sides):
+            if G.folds[k]:
+                fold_now(b"".join(G.folds[k]), side.cuda_stream)
+                G.folds[k] = []
+        done.extend(G.fold_writes)
+        G.fold_writes, G.flushes = [], 0
+    if G.on_write is not None and done:
+        _wrote(*done)
 
 
 class inplace_param_grads:
-    def __init__(self, side_stream=None, batch=8, on_write=None):
-        self.side_stream, self.batch, self.on_write = side_stream, batch, on_write
+    def __init__(self, side_stream=None, batch=8, on_write=None, fold_hint=None, fold_every=None):
+        self.side_stream, self.batch, self.on_write, self.fold_hint = side_stream, batch, on_write, fold_hint
+        self.fold_every = int(os.environ.get("AFD_FOLD_EVERY", 4)) if fold_every is None else fold_every
 
     def __enter__(self):
-        self.prev, self.prev_side, self.prev_sides, self.prev_cb = _GradMode.inplace, _GradMode.side, _GradMode.sides, _GradMode.on_write
+        G = _GradMode
+        self.prev = (G.inplace, G.side, G.sides, G.on_write, G.fold_hint, G.fold_every)
         ss = self.side_stream
         self.streams = [] if ss is None else (list(ss) if isinstance(ss, (list, tuple)) else [ss])
-        _GradMode.inplace, _GradMode.batch, _GradMode.on_write = True, self.batch, self.on_write
-        _GradMode.sides, _GradMode.side, _GradMode.turn = self.streams, (self.streams[0] if self.streams else None), 0
+        G.inplace, G.batch, G.on_write, G.fold_hint, G.fold_every = True, self.batch, self.on_write, self.fold_hint, max(1, self.fold_every)
+        G.sides, G.side, G.turn = self.streams, (self.streams[0] if self.streams else None), 0
+        G.folds, G.fold_writes, G.flushes = [[] for _ in self.streams], [], 0
 
     def __exit__(self, exc_type, *a):
+        G = _GradMode
         if self.streams:
             if exc_type is not None:
-                _GradMode.pending = []                                       # backward failed: drop what was queued
-            flush_wgrads()
+                G.pending, G.folds, G.fold_writes = [], [[] for _ in self.streams], []      # backward failed: drop what was queued
+            flush_wgrads(final=True)
             for st in self.streams:
                 torch.cuda.current_stream().wait_stream(st)                  # join: every dW is in .grad
-            _GradMode.launched = []                                          # buffers may be freed now (main-stream order)
-        _GradMode.inplace, _GradMode.side, _GradMode.sides, _GradMode.on_write = self.prev, self.prev_side, self.prev_sides, self.prev_cb
+            G.launched = []                                                  # buffers may be freed now (main-stream order)
+        G.inplace, G.side, G.sides, G.on_write, G.fold_hint, G.fold_every = self.prev
 
 
 def _direct(*params):
@@ -356,10 +403,10 @@ class GroupNormFiltAct(_Fn):
             L.afd_filt_act_bwd_gn(_p(x), _p(dy), _p(dx), _p(dres), B, C, H, W, _p(stats), _p(gamma), _p(beta), _p(res),
                                   ctx.tu.ptr, ctx.td.ptr, ctx.tu.N, _p(part), _stream())
             dg, db, acc, (dgamma, dbeta) = _gn_param_targets(C, gamma, beta, x.device)
-            if acc and _GradMode.side is not None:                     # the two column sums: off the critical path
-                pg, pb = _p(dg), _p(db)
-                defer_to_side_stream(lambda st, part=part, pg=pg, pb=pb: L.afd_colsum2(_p(part), pg, pb, B, C, 1, st), part,
-                                     writes=(gamma, beta))
+            if acc and _GradMode.side is not None:                     # the two column sums: folds, batched with the other layers'
+                pp = _p(part)                                          # part is (B, 2, C)
+                defer_to_side_stream(None, fold_desc(pp, _p(dg), C, B, stride=2 * C) + fold_desc(pp + 4 * C, _p(db), C, B, stride=2 * C),
+                                     part, writes=(gamma, beta))
             else:
                 L.afd_colsum2(_p(part), _p(dg), _p(db), B, C, acc, _stream())
                 if acc:
@@ -551,8 +598,8 @@ class Conv(_Fn):
                     _wrote(wp, bp)
                 else:
                     dwp, dbp = _p(wp.grad), (_p(bp.grad) if bp is not None else None)
-                    defer_to_side_stream(lambda st, x=x, dy=dy, ws=ws: L.afd_conv_wgrad(_p(x), _p(dy), dwp, dbp, B, Cin, Cout, H, W, ks, 1,
-                                                                                         _p(ws), st), x, dy, ws, writes=(wp, bp))
+                    defer_to_side_stream(lambda st, x=x, dy=dy, ws=ws: _wgrad_partials(x, dy, dwp, dbp, B, Cin, Cout, H, W, ks, ws, st),
+                                         x, dy, ws, writes=(wp, bp))
             else:
                 dw = torch.empty_like(w)
                 db = torch.empty(Cout, device=x.device, dtype=torch.float32) if ctx.has_bias else None
@@ -611,21 +658,15 @@ class LayerNormC(_Fn):
             return dres, None, None
         dy, dres = _c(dy), _c(dres)
         dx = torch.empty_like(x)
+        L = lib()
+        if _direct(gamma, ctx.beta_param):
+            # in-place mode: dx now; dgamma / dbeta (plane sums + fold) as a separate call, on the side stream when
+            # there is one (the same arithmetic either way: the two-stream step stays bit-identical)
+            L.afd_layernorm_c_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(dx), _p(dres), None, None, None, 0, _stream())
+            _ln_param_grads(x, dy, stats, gamma, ctx.beta_param, B, C, H * W)
+            return dx, None, None
         part = torch.empty(B, 2, C, device=x.device, dtype=torch.float32)
         dg, db, acc, (dgamma, dbeta) = _gn_param_targets(C, gamma, ctx.beta_param, x.device)
-        L = lib()
-        if acc:      # in-place mode: dx now; dgamma / dbeta (plane sums + fold) as a separate call, on the side stream when
-            #            there is one (the same arithmetic either way: the two-stream step stays bit-identical)
-            L.afd_layernorm_c_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(dx), _p(dres), None, None, None, 0, _stream())
-            pdg, pdb = _p(dg), _p(db)
-            params = lambda st, x=x, dy=dy, stats=stats, part=part: L.afd_layernorm_c_bwd_params(
-                _p(x), _p(dy), _p(stats), B, C, H * W, _p(part), pdg, pdb, 1, st)
-            if _GradMode.side is not None:
-                defer_to_side_stream(params, x, dy, stats, part, writes=(gamma, ctx.beta_param))
-            else:
-                params(_stream())
-                _wrote(gamma, ctx.beta_param)
-            return dx, None, None
         L.afd_layernorm_c_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(dx), _p(dres), _p(part), _p(dg), _p(db), acc,
                               _stream())
         return dx, dgamma, dbeta
@@ -669,6 +710,15 @@ def tok_supported(C):
     return bool(lib().afd_tok_supported(int(C)))
 
 
+def _wgrad_partials(x, dy, dwp, dbp, B, Cin, Cout, H, W, ks, ws, st):
+    """afd_conv_wgrad_partials: the slab producer now, its fold descriptor(s) returned for the batched fold."""
+    import ctypes
+    buf = ctypes.create_string_buffer(112)
+    n = ctypes.c_int(0)
+    lib().afd_conv_wgrad_partials(_p(x), _p(dy), dwp, dbp, B, Cin, Cout, H, W, ks, 1, _p(ws), ctypes.addressof(buf), ctypes.addressof(n), st)
+    return buf.raw[:56 * n.value]
+
+
 def _linear_grads(x, dy, w, b, B, C_in, C_out, H, W, need_w=True):
     """Weight / bias gradients of a token-wise Linear (= 1x1 convolution) y = w x + b from its input x (B,C_in,H,W) and
     dy (B,C_out,H,W).  In-place mode: accumulated straight into w.grad / b.grad, on the side stream when there is one
@@ -678,11 +728,11 @@ def _linear_grads(x, dy, w, b, B, C_in, C_out, H, W, need_w=True):
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
     if _direct(w, b):
         dwp, dbp = _p(w.grad), (_p(b.grad) if b is not None else None)
-        fn = lambda st, x=x, dy=dy, ws=ws: L.afd_conv_wgrad(_p(x), _p(dy), dwp, dbp, B, C_in, C_out, H, W, 1, 1, _p(ws), st)
         if _GradMode.side is not None:
-            defer_to_side_stream(fn, x, dy, ws, writes=(w, b))
+            defer_to_side_stream(lambda st, x=x, dy=dy, ws=ws: _wgrad_partials(x, dy, dwp, dbp, B, C_in, C_out, H, W, 1, ws, st),
+                                 x, dy, ws, writes=(w, b))
         else:
-            fn(_stream())
+            L.afd_conv_wgrad(_p(x), _p(dy), dwp, dbp, B, C_in, C_out, H, W, 1, 1, _p(ws), _stream())
             _wrote(w, b)
         return None, None
     dw = torch.empty_like(w)
@@ -698,12 +748,14 @@ def _ln_param_grads(x, dy, stats, gamma, beta, B, C, HW):
     part = torch.empty(B, 2, C, device=x.device, dtype=torch.float32)
     dg, db, acc, (dgamma, dbeta) = _gn_param_targets(C, gamma, beta, x.device)
     pdg, pdb = _p(dg), _p(db)
-    fn = lambda st, x=x, dy=dy, stats=stats, part=part: L.afd_layernorm_c_bwd_params(
-        _p(x), _p(dy), _p(stats), B, C, HW, _p(part), pdg, pdb, acc, st)
     if acc and _GradMode.side is not None:
+        def fn(st, x=x, dy=dy, stats=stats, part=part):                  # the plane pass now, the two column sums with the batched fold
+            L.afd_layernorm_c_bwd_partials(_p(x), _p(dy), _p(stats), B, C, HW, _p(part), st)
+            pp = _p(part)
+            return fold_desc(pp, pdg, C, B, stride=2 * C) + fold_desc(pp + 4 * C, pdb, C, B, stride=2 * C)
         defer_to_side_stream(fn, x, dy, stats, part, writes=(gamma, beta))
     else:
-        fn(_stream())
+        L.afd_layernorm_c_bwd_params(_p(x), _p(dy), _p(stats), B, C, HW, _p(part), pdg, pdb, acc, _stream())
         if acc:
             _wrote(gamma, beta)
     return dgamma, dbeta

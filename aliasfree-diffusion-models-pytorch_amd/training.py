@@ -199,6 +199,18 @@ class GradAllReduce:
             if self._left[k] == 0:
                 self._launch(k)
 
+    def would_complete(self, params):
+        """True if reporting `params` as written would complete (and so start the exchange of) some bucket: the hint that
+        makes ops.flush_wgrads launch its queued gradient folds now rather than batch them further."""
+        if self.world == 1:
+            return False
+        need = {}
+        for p_ in params:
+            k = self._bucket_of.get(id(p_))
+            if k is not None and id(p_) not in self._seen and k not in self._launched:
+                need.setdefault(k, set()).add(id(p_))
+        return any(len(v) == self._left[k] for k, v in need.items())
+
     def _launch(self, k):
         if k in self._launched:
             return
@@ -287,7 +299,8 @@ class TrainStep:
             if overlap:
                 self.ddp.begin_step()                  # bucket all-reduces start during backward, as their gradients complete
             with ops.inplace_param_grads(self.wgrad_stream, self.wgrad_batch,   # weight gradients add straight into the flat .grad views
-                                         on_write=self.ddp.wrote if overlap else None):
+                                         on_write=self.ddp.wrote if overlap else None,
+                                         fold_hint=self.ddp.would_complete if overlap else None):
                 loss.backward()
                 if overlap:
                     self.ddp.backward_done()

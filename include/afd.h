@@ -145,6 +145,31 @@ int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias /* o
                    int B, int Cin, int Cout, int H, int W, int ksize, int accumulate,
                    void* workspace, afd_stream_t stream);
 
+/* ---- the deterministic tail of every parameter gradient, batched (csrc/fold.hip) ----------------------------------
+ *      backward of nn.Conv2d / nn.Linear / nn.GroupNorm / nn.LayerNorm parameters: ddpm_utils.py:59-66,84-88,112-118
+ * A fold: dst[(j % inner) * rstride + j / inner] (+)= sum_{s < splits} part[s * stride + j], j < n, fixed order, no
+ * atomics (identity map: inner = n, rstride = 1; [tap][plane] slabs -> OIHW: inner = n / 9, rstride = 9).
+ * afd_fold_batched folds any number of them in ceil(n / 56) launches (descs: HOST array; the descriptors travel as
+ * kernel arguments, so the call is legal under stream capture and needs no device table).  The result of a fold does
+ * not depend on what it is batched with.
+ * afd_conv_wgrad_partials = afd_conv_wgrad without its final fold: launches the slab producer and writes the fold
+ * descriptor(s) (weights, then bias) to folds_out[0..*n_folds) (HOST, room for 2) for a later afd_fold_batched ON THE
+ * SAME STREAM; the workspace must stay alive until that fold has run.  Shapes whose kernel has no slab stage are
+ * completed at once and report *n_folds = 0. */
+typedef struct afd_fold_desc {
+  const float* part;     /* partial slabs */
+  float* dst;
+  long n;                /* elements per slab */
+  long stride;           /* elements between consecutive slabs (>= n) */
+  long inner, rstride;   /* element map, see above */
+  int splits;            /* number of slabs */
+  int accumulate;        /* != 0: add into dst */
+} afd_fold_desc;         /* 56 bytes */
+int afd_fold_batched(const afd_fold_desc* descs, int n, afd_stream_t stream);
+int afd_conv_wgrad_partials(const float* x, const float* dy, float* dw, float* dbias /* or NULL */,
+                            int B, int Cin, int Cout, int H, int W, int ksize, int accumulate,
+                            void* workspace, afd_fold_desc* folds_out, int* n_folds, afd_stream_t stream);
+
 /* Winograd F(2x2,3x3) form of the 3x3 forward / dgrad (same results up to fp32 re-association: every product
  * and sum is fp32; 16 multiplies per 2x2 output tile and channel pair instead of 36).  Covers the square
  * 64x64 ... 4x4 maps with Cin % 8 == 0 and Cout % 32 == 0 (dgrad: roles swapped).
@@ -200,6 +225,10 @@ int afd_layernorm_c_bwd(const float* x, const float* dy, const float* stats, int
 int afd_layernorm_c_bwd_params(const float* x, const float* dy, const float* stats, int B, int C, int HW,
                                float* dgamma_dbeta_partial /* (B,2,C) */, float* dgamma, float* dbeta, int accumulate,
                                afd_stream_t stream);
+/* the plane pass of afd_layernorm_c_bwd_params alone: part (B,2,C) = per-sample sums over the pixels of dy*xhat and dy;
+ * the caller folds them (afd_fold_batched: two descriptors, n = C, stride = 2C, splits = B) */
+int afd_layernorm_c_bwd_partials(const float* x, const float* dy, const float* stats, int B, int C, int HW, float* part,
+                                 afd_stream_t stream);
 
 /* ---- F10: multi-head self-attention core (softmax(QK^T/sqrt(d))V), flash-style ------------------
  * ddpm_utils.py:71 (nn.MultiheadAttention, batch_first, 4 heads).  qkv (B,3C,L): channel

@@ -489,6 +489,71 @@ def test_conv_wgrad_full_batch_matches_double_precision(A):
     assert rel_l2(gd[1].cpu(), go[1]) < 5e-6
 
 
+
+def test_fold_batched_maps_and_batching_independence(A):
+    """afd_fold_batched (csrc/fold.hip): the three element maps against fp64 sums, vector and scalar forms, and the result of a
+    fold must not depend on what it is batched with (one launch of 70 descriptors == 70 launches of one, bit for bit)."""
+    afdm, ops, dev = A
+    g = _g(5)
+    cases = []                                     # (slabs (S, stride), n, inner, rstride, expected dst length)
+    for (n, S, T) in ((9 * 64 * 32, 37, 9), (9 * 32 * 32, 8, 9), (128 * 64, 16, 1), (96, 13, 1), (27 * 32, 5, 9), (256, 256, 1)):
+        cases.append((torch.randn(S, n, generator=g), n, n // T, T))
+    part2 = torch.randn(23, 2, 48, generator=g)    # (B, 2, C) plane partials: two descriptors over one buffer, stride 2C
+    descs, wants, outs, keep = [], [], [], []
+    for rep in range(10):                          # 70 descriptors: two launches (56 + 14)
+        for slabs, n, inner, rstride in cases:
+            d = slabs.to(dev)
+            out = torch.full((n,), 0.5, device=dev)
+            want = slabs.double().sum(0).reshape(rstride, inner).t().reshape(-1) + 0.5      # j = q*inner + r -> dst[r*rstride + q]
+            descs.append(ops.fold_desc(d.data_ptr(), out.data_ptr(), n, slabs.shape[0], inner=inner, rstride=rstride, accumulate=1))
+            wants.append(want); outs.append(out); keep.append(d)
+        d2 = part2.to(dev)
+        o2 = torch.empty(48, device=dev)
+        descs.append(ops.fold_desc(d2.data_ptr() + 4 * 48, o2.data_ptr(), 48, 23, stride=96, accumulate=0))
+        wants.append(part2[:, 1].double().sum(0)); outs.append(o2); keep.append(d2)
+    ops.fold_now(b"".join(descs))
+    torch.cuda.synchronize()
+    for k, (o, w) in enumerate(zip(outs, wants)):
+        check("fold_batched vs fp64", o.cpu(), w, 1e-6, k)
+    batched = [o.clone() for o in outs]
+    for o in outs:
+        o.fill_(0.5)
+    for dsc in descs:
+        ops.fold_now(dsc)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(batched, outs))
+    with pytest.raises(afdm.AfdError, match="bad descriptor"):
+        ops.fold_now(ops.fold_desc(keep[0].data_ptr(), outs[0].data_ptr(), 100, 3, inner=7))
+
+
+@pytest.mark.parametrize("case", [(8, 64, 64, 16, 16, 3, False), (8, 3, 32, 32, 32, 3, False), (8, 32, 96, 16, 16, 1, True),
+                                  (4, 12, 40, 8, 8, 3, False), (3, 16, 24, 6, 10, 3, False), (256, 128, 128, 8, 8, 3, False)])
+def test_conv_wgrad_partials_plus_fold_equals_conv_wgrad(A, case):
+    """afd_conv_wgrad_partials + a later afd_fold_batched == afd_conv_wgrad, bit for bit (both fold through the same kernel);
+    shapes without a slab stage report no fold and are complete at once."""
+    import ctypes
+    afdm, ops, dev = A
+    L = afdm.lib()
+    B, Cin, Cout, H, W, ks, bias = case
+    g = _g(sum(case))
+    x, dy = torch.randn(B, Cin, H, W, generator=g).to(dev), torch.randn(B, Cout, H, W, generator=g).to(dev)
+    ws = torch.empty(max(L.afd_conv_wgrad_workspace_bytes(B, Cin, Cout, H, W, ks) // 4, 1), device=dev)
+    P = lambda t: t.data_ptr()
+    dw0, db0 = torch.ones(Cout, Cin, ks, ks, device=dev), torch.ones(Cout, device=dev)
+    dw1, db1 = torch.ones_like(dw0), torch.ones_like(db0)
+    L.afd_conv_wgrad(P(x), P(dy), P(dw0), P(db0) if bias else None, B, Cin, Cout, H, W, ks, 1, P(ws), ops._stream())
+    torch.cuda.synchronize()
+    ws.fill_(float("nan"))
+    buf, n = ctypes.create_string_buffer(112), ctypes.c_int(-1)
+    L.afd_conv_wgrad_partials(P(x), P(dy), P(dw1), P(db1) if bias else None, B, Cin, Cout, H, W, ks, 1, P(ws), ctypes.addressof(buf),
+                              ctypes.addressof(n), ops._stream())
+    assert 0 <= n.value <= 2
+    if n.value:
+        ops.fold_now(buf.raw[:56 * n.value])
+    torch.cuda.synchronize()
+    assert torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    assert (n.value == 0) == (case[4] == 10)                      # only the plane the tiler cannot cut has no slab stage
+
 # ---------------------------------------------------------------------------------------------
 # F10 attention block pieces
 # ---------------------------------------------------------------------------------------------
