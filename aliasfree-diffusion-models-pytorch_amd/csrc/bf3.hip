@@ -218,6 +218,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf3(const float* __restrict__ x, 
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static int g_bf3_mode = 0;          // afd_debug_conv_path 80 / 81 / 82: by the rule / off / wherever the shape is covered
 void bf3_set_mode(int m) { g_bf3_mode = m; }
+static int g_direct_bf3 = 0;        // afd_debug_conv_path 76 / 77: the direct form is f16x2 (h2.hip, default) / bf16x3 (this file)
+void direct_form_set(int m) { g_direct_bf3 = m; }
+bool direct_form_is_bf3() { return g_direct_bf3 != 0; }
 static int g_bf3_nblk = 0;          // tools/micro/bf3_abl.hip: force the channel blocks per workgroup (0 = by the rule)
 void bf3_set_nblk(int n) { g_bf3_nblk = n; }
 // channel blocks per workgroup: as many as divide N while the launch still has two workgroups per CU (four only on 16 x 16

@@ -533,6 +533,11 @@ static void wgrad_bf3_tile(int Cin, int Cout, long nt, int* bn, int* bk) {
   *bk = (Cin % 64 == 0 && Cout % 64 && (force ? force >= 64 : true)) ? 64 : 32;
 }
 
+void wgrad_bf3_tile_for(int Cin, int Cout, long nt, int* bn, int* bk) { wgrad_bf3_tile(Cin, Cout, nt, bn, bk); }   // (h2_wgrad.hip shares the plan)
+static int g_wg_arith_bf3 = 0;     // afd_debug_conv_path 78 / 79: the 3x3 weight gradient's arithmetic is f16x2 (h2_wgrad.hip, default) / bf16x3 (this file)
+void wgrad_arith_set(int m) { g_wg_arith_bf3 = m; }
+bool wgrad_arith_is_bf3() { return g_wg_arith_bf3 != 0; }
+
 // plan: the number of slabs (0 = not covered / not chosen) and the tiles per split
 int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles) {
   if (g_wgbf3_mode == 1) return 0;

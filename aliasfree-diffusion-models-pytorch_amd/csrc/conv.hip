@@ -814,6 +814,8 @@ void wino_set_mode(int m);
 void wino_weights_launch(const float* w, float* Uf, float* Ud, int Cin, int Cout, int kinds, hipStream_t s);
 bool bf3_ok(int B, int K, int N, int H, int W);       // bf3.hip: the direct bf16x3 form of a 3x3 layer
 void bf3_set_mode(int m);
+void direct_form_set(int m);
+bool direct_form_is_bf3();
 void wino_weights_batched_launch(const afd_wino_desc* descs, const int* wg_desc, int n_wg, hipStream_t s);
 void wino_set_grid(int g);
 int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, int* cps, int* nchunks);
@@ -821,6 +823,10 @@ int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, in
 int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles);
 int wgrad_bf3(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
 void wgrad_bf3_set_mode(int m);
+void wgrad_arith_set(int m);
+bool wgrad_arith_is_bf3();
+// h2_wgrad.hip: the same on the fp16 matrix cores (two-piece splits, online scaling; the plan is shared)
+int wgrad_h2(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
 // ends.hip: the 1x1 output layer and its dgrad as streaming vector kernels
 bool ends_fwd(const float* x, const float* w, const float* bias, const float* res, float* y, int B, int Cin, int Cout, int H, int W,
               int ksize, int act, hipStream_t s);
@@ -943,6 +949,8 @@ int afd_debug_conv_path(int mode) {
   if (mode >= 92 && mode <= 93) { ends_set_mode(mode - 92); return AFD_OK; }   // output-layer streaming kernels: 92 = by rule (default), 93 = off
   if (mode >= 88 && mode <= 89) { pw_wgrad_bf3_set_mode(mode - 88); return AFD_OK; }   // bf16x3 1x1 wgrad: 88 = by rule (default), 89 = off
   if (mode >= 84 && mode <= 86) { wgrad_bf3_set_mode(mode - 84); return AFD_OK; }   // bf16x3 3x3 wgrad: 84 = by rule (default), 85 = off, 86 = wherever covered
+  if (mode >= 78 && mode <= 79) { wgrad_arith_set(mode - 78); return AFD_OK; }   // arithmetic of the matrix-core 3x3 weight gradient: 78 = f16x2 (default), 79 = bf16x3 (round 2)
+  if (mode >= 76 && mode <= 77) { direct_form_set(mode - 76); return AFD_OK; }   // arithmetic of the direct 3x3 forward / dgrad: 76 = f16x2 (default), 77 = bf16x3 (round 2)
   if (mode >= 80 && mode <= 82) { bf3_set_mode(mode - 80); return AFD_OK; }   // direct bf16x3 3x3 kernel: 80 = by rule (default), 81 = off, 82 = wherever covered
   if (mode >= 8 && mode <= 10) { pw_set_mode(mode - 8); return AFD_OK; }     // 1x1 streaming kernel: 8 = by rule (default), 9 = off, 10 = forced
   if (mode >= 100000 && mode < 200000) { wino_set_grid(mode - 100000); return AFD_OK; }   // Winograd persistent grid size (0 = default)
@@ -1001,12 +1009,13 @@ size_t afd_conv3x3_wino_workspace_bytes(int B, int Cin, int Cout, int H, int W, 
 
 int afd_conv3x3_weight_kinds(int B, int Cin, int Cout, int H, int W) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
-  return (bf3_ok(B, Cin, Cout, H, W) ? 1 : 0) | (bf3_ok(B, Cout, Cin, H, W) ? 2 : 0);
+  const int k = (bf3_ok(B, Cin, Cout, H, W) ? 1 : 0) | (bf3_ok(B, Cout, Cin, H, W) ? 2 : 0);
+  return k && direct_form_is_bf3() ? k | 4 : k;
 }
 
 int afd_conv3x3_wino_weights(const float* w, float* u_fwd, float* u_dgrad, int Cin, int Cout, int kinds, afd_stream_t st) {
   AFD_REQUIRE(w && (u_fwd || u_dgrad) && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, "afd_conv3x3_wino_weights: bad argument");
-  AFD_REQUIRE(kinds >= 0 && kinds <= 3 && (!(kinds & 3) || (Cin % 16 == 0 && Cout % 16 == 0)), "afd_conv3x3_wino_weights: bad kinds %d", kinds);
+  AFD_REQUIRE(kinds >= 0 && kinds <= 7 && (!(kinds & 4) || (kinds & 3)) && (!(kinds & 3) || (Cin % 16 == 0 && Cout % 16 == 0)), "afd_conv3x3_wino_weights: bad kinds %d", kinds);
   wino_weights_launch(w, u_fwd, u_dgrad, Cin, Cout, kinds, as_stream(st));
   return check_launch("afd_conv3x3_wino_weights");
 }
@@ -1017,18 +1026,31 @@ int afd_conv3x3_wino_weights_batched(const afd_wino_desc* descs, const int* wg_d
   return check_launch("afd_conv3x3_wino_weights_batched");
 }
 
+// the weight image in the workspace was built for `kinds` (afd_conv3x3_weight_kinds at build time): it must be the form this
+// call is about to read -- the rule depends on the batch size and on the debug switches
+static int check_kinds(const char* who, int kinds, int B, int Cin, int Cout, int H, int W, int dgrad) {
+  const int now = afd_conv3x3_weight_kinds(B, Cin, Cout, H, W);
+  const int bit = dgrad ? 2 : 1;
+  AFD_REQUIRE(kinds >= 0 && (kinds & bit) == (now & bit) && (!(now & bit) || (kinds & 4) == (now & 4)),
+              "%s: the weight image was built as kinds %d, but a call with (B %d, %d -> %d, %dx%d) under the current settings reads kinds %d "
+              "(rebuild it: afd_conv3x3_weight_kinds depends on the batch size and on afd_debug_conv_path)", who, kinds, B, Cin, Cout, H, W, now);
+  return AFD_OK;
+}
+
 int afd_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
-                         int B, int Cin, int Cout, int H, int W, int act, void* workspace, int weights_ready, afd_stream_t st) {
+                         int B, int Cin, int Cout, int H, int W, int act, void* workspace, int weights_ready, int kinds, afd_stream_t st) {
   AFD_REQUIRE(x && w && y && workspace && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "afd_conv3x3_wino_fwd: bad argument");
   AFD_REQUIRE(act == 0 || act == 1, "afd_conv3x3_wino_fwd: act must be 0 or 1");
+  if (weights_ready && check_kinds("afd_conv3x3_wino_fwd", kinds, B, Cin, Cout, H, W, 0) != AFD_OK) return AFD_EINVAL;
   AFD_REQUIRE(wino_conv(x, w, bias, res, y, static_cast<float*>(workspace), B, Cin, Cout, H, W, act, false, weights_ready != 0, as_stream(st)),
               "afd_conv3x3_wino_fwd: shape (%d,%d->%d,%dx%d) is not covered (afd_conv3x3_wino_workspace_bytes returns 0 for it)", B, Cin, Cout, H, W);
   return check_launch("afd_conv3x3_wino_fwd");
 }
 
 int afd_conv3x3_wino_dgrad(const float* dy, const float* w, float* dx, const float* add_to_dx, int B, int Cin, int Cout, int H, int W,
-                           void* workspace, int weights_ready, afd_stream_t st) {
+                           void* workspace, int weights_ready, int kinds, afd_stream_t st) {
   AFD_REQUIRE(dy && w && dx && workspace && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "afd_conv3x3_wino_dgrad: bad argument");
+  if (weights_ready && check_kinds("afd_conv3x3_wino_dgrad", kinds, B, Cin, Cout, H, W, 1) != AFD_OK) return AFD_EINVAL;
   AFD_REQUIRE(wino_conv(dy, w, nullptr, add_to_dx, dx, static_cast<float*>(workspace), B, Cout, Cin, H, W, 0, true, weights_ready != 0, as_stream(st)),
               "afd_conv3x3_wino_dgrad: shape (%d,%d->%d,%dx%d) is not covered", B, Cin, Cout, H, W);
   return check_launch("afd_conv3x3_wino_dgrad");
@@ -1063,7 +1085,7 @@ int afd_conv_wgrad_form(int B, int Cin, int Cout, int H, int W, int ksize) {
   int a, b, c, d;
   if (ksize == 1) return pw_wgrad_bf3_plan(B, Cin, Cout, H * W, &a, &b, &c, &d) ? 2 : 0;
   if (ksize != 3) return 0;
-  if (wgrad_bf3_plan(B, Cin, Cout, H, W, &a, &b)) return 2;
+  if (wgrad_bf3_plan(B, Cin, Cout, H, W, &a, &b)) return wgrad_arith_is_bf3() ? 2 : 4;
   if (wgrad_cin3_plan(B, Cin, Cout, H, W)) return 3;
   return wgrad_wino_plan(B, Cin, Cout, H, W, &a, &b, &c, &d) ? 1 : 0;
 }
@@ -1077,7 +1099,7 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw, float* db
   int rc = AFD_OK;
   if (ksize == 3 && !dbias && workspace) {                               // bf16x3 form on the matrix pipe, else Winograd F(3x3, 2x2): 16 multiplies per tile instead of 36
     float* part = static_cast<float*>(workspace);
-    int slabs = wgrad_bf3(x, dy, part, B, Cin, Cout, H, W, s);
+    int slabs = wgrad_arith_is_bf3() ? wgrad_bf3(x, dy, part, B, Cin, Cout, H, W, s) : wgrad_h2(x, dy, part, B, Cin, Cout, H, W, s);
     if (!slabs) slabs = wgrad_cin3(x, dy, part, B, Cin, Cout, H, W, s);
     if (!slabs) slabs = wgrad_wino(x, dy, part, B, Cin, Cout, H, W, s);
     if (slabs) {

@@ -1,0 +1,254 @@
+// h2.hip -- F5: 3x3 (pad 1) convolution forward / dgrad as a DIRECT implicit GEMM on the fp16 matrix cores at fp32-class
+// accuracy with TWO-piece splits and online power-of-two scaling (round 3; h2_common.h has the arithmetic and its error bound).
+//
+// Same tiling as round 2's bf16x3 kernel (bf3.hip, kept for A/B: afd_debug_conv_path 76 / 77): a workgroup owns NBLK x 32
+// output channels x 128 output pixels (whole rows of one image, or whole images); per chunk of 32 input channels the haloed
+// input pixels go global -> registers -> scale -> split -> LDS as Xp[piece 2][k/8][pixel][8 fp16]; a B fragment is one
+// ds_read_b128 at (pixel + tap offset); A fragments come straight from global memory / L2 out of the weight image
+// Wp[piece 2][tap][k/8][n][8 fp16].  THREE v_mfma_f32_16x16x32_f16 per (tap, chunk, 16 x 16 block) instead of six.
+//
+// Online scale: before a staged chunk is split, the workgroup takes the maximum magnitude of the values its threads hold
+// (a DPP wave maximum, four floats through LDS, folded into the barrier that already separates the previous chunk's fragment
+// reads from this chunk's stores), and if the chunk would leave fp16's range under the current scale, lowers the scale and
+// multiplies the accumulators by the ratio.  The epilogue multiplies by 1 / (s_x s_w[n]).  All factors are powers of two.
+#include <algorithm>
+#include <cstdint>
+#include "common.h"
+#include "h2_common.h"
+
+namespace afd {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__global__ __launch_bounds__(256) void h2_wscale(const float* __restrict__ w, void* Wf, void* Wd, int Cin, int Cout) {
+  h2_wscale_rows(w, Wf, Wd, Cin, Cout, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+__global__ __launch_bounds__(256) void h2_weights(const float* __restrict__ w, void* Wf, void* Wd, int Cin, int Cout) {
+  h2_weights_block(w, Wf, Wd, Cin, Cout, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// ---- geometry of a 128-pixel workgroup tile on an S x S map (as bf3.hip) -------------------------------------------------
+template <int S> struct H2Geo {
+  static constexpr int TP = 128;
+  static constexpr int IPT = S * S >= TP ? 1 : TP / (S * S);         // images per tile
+  static constexpr int R = S * S >= TP ? TP / S : S;                 // output rows per image in the tile
+  static constexpr int TPI = S * S >= TP ? S * S / TP : 1;           // tiles per image
+  static constexpr int Wp = S + 2, IMG = (R + 2) * Wp, NPIX = IPT * IMG;
+  static constexpr int NPP = (NPIX + 15) / 16 * 16;                  // channel-group stride = whole 64-bank rows: the four groups of a b128 read never collide
+  static constexpr int KG = 4;                                       // 8-channel groups per 32-channel chunk
+  static constexpr int TASKS = KG * NPIX, NE = (TASKS + 255) / 256;  // staging tasks (pixel record, channel group) per thread
+};
+
+template <int S, int NBLK>
+__global__ __launch_bounds__(256, 2) void conv_h2(const float* __restrict__ x, const h8* __restrict__ Wp,
+                                                  const float* __restrict__ bias, const float* __restrict__ res,
+                                                  float* __restrict__ y, int B, int K, int N, int act) {
+  using G = H2Geo<S>;
+  // v_mfma_f32_16x16x32_f16: lane (row / column = l & 15, k group = l >> 4) holds k = 8 (l >> 4) + j -- one 16-byte
+  // record of the weight image (A) or of the LDS pixel image (B); accumulator: column = l & 15, row = 4 (l >> 4) + reg.
+  constexpr int PSW = 2 * NBLK, NPIX = G::NPIX, NPP = G::NPP, NE = G::NE;   // 16-pixel sub-blocks per wave: 4 / NBLK waves share 128 pixels
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  h8* Xp = reinterpret_cast<h8*>(smem_raw);                          // [piece 2][kg 4][NPP] records
+  float* wmax = reinterpret_cast<float*>(smem_raw + (size_t)2 * G::KG * NPP * 16);   // the four waves' chunk maxima
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kgl = lane >> 4, l15 = lane & 15;
+  const int nb = wv % NBLK, pgrp = wv / NBLK;                        // this wave's 32-channel block / its group of pixel sub-blocks
+  const int tile = blockIdx.x, n0 = (blockIdx.y * NBLK + nb) * 32;
+  const int img0 = G::IPT > 1 ? tile * G::IPT : tile / G::TPI;
+  const int row0 = G::IPT > 1 ? 0 : (tile % G::TPI) * G::R;
+  const int HW = S * S;
+
+  // ---- staging plan: task e of this thread = (record ridx, channel group kg)
+  int s_src[NE];                 // element offset of channel (8 kg) at the record's pixel inside image img0 (or -1: zero)
+  int s_dst[NE];                 // record index kg * NPP + ridx (or -1: no task)
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int t = tid + 256 * e;
+    s_src[e] = -1; s_dst[e] = -1;
+    if (t < G::TASKS) {
+      const int kg = t / NPIX, ridx = t - kg * NPIX;
+      const int i = ridx / G::IMG, rem = ridx - i * G::IMG, rr = rem / G::Wp, cc = rem - rr * G::Wp;
+      const int yy = row0 + rr - 1, xx = cc - 1, b = img0 + i;
+      s_dst[e] = kg * NPP + ridx;
+      if (yy >= 0 && yy < S && xx >= 0 && xx < S && b < B) s_src[e] = ((i * K + 8 * kg) * S + yy) * S + xx;
+    }
+  }
+  const float* xb = x + (long)img0 * K * HW;
+  float xr[NE][8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const float* p = xb + (long)k0 * HW + (s_src[e] >= 0 ? s_src[e] : 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xr[e][j] = s_src[e] >= 0 ? p[(long)j * HW] : 0.f;
+    }
+  };
+  auto chunk_amax = [&]() {                                           // this wave's share of the staged chunk's max |x| -> wmax[wv]
+    float m = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(xr[e][j]));
+    m = wave_amax(m);
+    if (lane == 0) wmax[wv] = m;
+  };
+  auto commit = [&](float s) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      if (s_dst[e] < 0) continue;
+      h8 p0, p1;
+      h2_split8(xr[e], s, p0, p1);
+      Xp[s_dst[e]] = p0;
+      Xp[G::KG * NPP + s_dst[e]] = p1;
+    }
+  };
+
+  // ---- B fragment base per 16-pixel sub-block: record of (pixel, tap (0,0)) in this lane's channel group
+  int bbase[PSW];
+#pragma unroll
+  for (int ps = 0; ps < PSW; ++ps) {
+    const int q = (pgrp * PSW + ps) * 16 + l15;
+    const int i = q / (G::R * S), rem = q - i * (G::R * S), r = rem / S, c = rem - r * S;
+    bbase[ps] = kgl * NPP + i * G::IMG + r * G::Wp + c;
+  }
+  f32x4 acc[2][PSW];
+#pragma unroll
+  for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+    for (int ps = 0; ps < PSW; ++ps) acc[ns][ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- A fragments: records (tap * K/8 + k/8) * N + n, k/8 = 4 ks + (l >> 4), n = n0 + 16 ns + (l & 15)
+  const int KS = K >> 5, nit = KS * 9;                               // (k-step of 32 channels, tap) groups
+  const long pstride = (long)9 * (K >> 3) * N;                       // records per piece
+  const h8* wl = Wp + (long)kgl * N + n0 + l15;
+  auto a_load = [&](h8 (&a)[2][2], int it) {
+    const int ks = it / 9, tap = it - ks * 9;
+    const long r = ((long)tap * (K >> 3) + 4 * ks) * N;
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns) { a[ns][0] = wl[r + 16 * ns]; a[ns][1] = wl[pstride + r + 16 * ns]; }
+  };
+  // A queue, AQ groups deep: vector-memory results return in order, so a fragment requested after the next chunk's x loads
+  // (HBM latency) cannot be used before those have landed
+  constexpr int AQ = 2;
+  h8 aq[AQ][2][2];
+#pragma unroll
+  for (int d = 0; d < AQ; ++d)
+    if (d < nit) a_load(aq[d], d);
+
+  float sx = __uint_as_float(kH2ScaleCapBits);                        // the running scale of x: the cap until a chunk says otherwise
+  fetch(0);
+  int it = 0;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    chunk_amax();
+    __syncthreads();                                                  // the previous chunk's fragment reads are done; the four maxima are visible
+    {
+      const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      const float sn = fminf(sx, h2_scale_for(m));
+      if (sn != sx) {                                                 // (uniform) this chunk would overflow: lower the scale, carry the sums over
+        const float f = sn * h2_inv_pow2(sx);
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+          for (int ps = 0; ps < PSW; ++ps) acc[ns][ps] *= f;
+        sx = sn;
+      }
+    }
+    commit(sx);
+    __syncthreads();
+    // B fragments one (tap, pixel sub-block) unit ahead of the multiplies; the order is pinned (the scheduler would
+    // otherwise hoist every read of the unrolled loop to the top and spill)
+    h8 bc[2], bn[2];
+    bc[0] = Xp[bbase[0]]; bc[1] = Xp[G::KG * NPP + bbase[0]];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      h8 a[2][2];
+#pragma unroll
+      for (int ns = 0; ns < 2; ++ns) { a[ns][0] = aq[0][ns][0]; a[ns][1] = aq[0][ns][1]; }
+#pragma unroll
+      for (int d = 0; d + 1 < AQ; ++d)
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns) { aq[d][ns][0] = aq[d + 1][ns][0]; aq[d][ns][1] = aq[d + 1][ns][1]; }
+      if (it + AQ < nit) a_load(aq[AQ - 1], it + AQ);
+      ++it;
+      if (tap == 0 && k0 + 32 < K) fetch(k0 + 32);                    // in flight during the multiplies, behind the next tap's A request
+#pragma unroll
+      for (int ps = 0; ps < PSW; ++ps) {
+        const int u = tap * PSW + ps + 1;                            // the next unit
+        if (u < 9 * PSW) {
+          const int tn = u / PSW, pn = u % PSW;
+          const int o = bbase[pn] + (tn / 3) * G::Wp + (tn % 3);
+          bn[0] = Xp[o]; bn[1] = Xp[G::KG * NPP + o];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns) {
+          acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ns][0], bc[0], acc[ns][ps], 0, 0, 0);
+          acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ns][1], bc[0], acc[ns][ps], 0, 0, 0);
+          acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ns][0], bc[1], acc[ns][ps], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bc[0] = bn[0]; bc[1] = bn[1];
+      }
+    }
+  }
+
+  // ---- epilogue: accumulator rows = output channels n0 + 16 ns + 4 (l >> 4) + reg, column = this lane's pixel
+  const float* isw = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(Wp) + h2_scale_offset_bytes(K, N));
+  const float isx = h2_inv_pow2(sx);
+#pragma unroll
+  for (int ps = 0; ps < PSW; ++ps) {
+    const int q = (pgrp * PSW + ps) * 16 + l15;
+    const int i = q / (G::R * S), rem = q - i * (G::R * S), r = rem / S, c = rem - r * S;
+    const int b = img0 + i;
+    if (b >= B) continue;
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns) {
+      const int nn = n0 + 16 * ns + 4 * kgl;
+      const long o = ((long)b * N + nn) * HW + (row0 + r) * S + c;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float v = (acc[ns][ps][rg] * isx) * isw[nn + rg];
+        if (bias) v += bias[nn + rg];
+        if (act == 1) v = gelu_erf(v);
+        if (res) v += res[o + (long)rg * HW];
+        y[o + (long)rg * HW] = v;
+      }
+    }
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------
+// channel blocks per workgroup: as bf3.hip (as many as divide N while the launch keeps two workgroups per CU)
+static int h2_nblk(long tiles, int N, int S) {
+  for (int nb = S == 16 ? 4 : 2; nb > 1; nb >>= 1)
+    if (N % (32 * nb) == 0 && tiles * (N / (32 * nb)) >= 512) return nb;
+  return 1;
+}
+
+void h2_weights_launch(const float* w, void* Wf, void* Wd, int Cin, int Cout, hipStream_t s) {
+  const int rows8 = (Wf ? Cout / 8 : 0) + (Wd ? Cin / 8 : 0);
+  hipLaunchKernelGGL(h2_wscale, dim3((unsigned)((rows8 + 3) / 4)), dim3(256), 0, s, w, Wf, Wd, Cin, Cout);
+  hipLaunchKernelGGL(h2_weights, dim3((unsigned)((Cin * Cout / 64 + 3) / 4)), dim3(256), 0, s, w, Wf, Wd, Cin, Cout);
+}
+
+template <int S, int NBLK>
+static void h2_launch_t(const float* x, const void* Wp, const float* bias, const float* res, float* y, int B, int K, int N, int act,
+                        hipStream_t s) {
+  using G = H2Geo<S>;
+  const size_t lds = (size_t)2 * G::KG * G::NPP * 16 + 16;
+  const long tiles = G::IPT > 1 ? ((long)B + G::IPT - 1) / G::IPT : (long)B * G::TPI;
+  hipLaunchKernelGGL((conv_h2<S, NBLK>), dim3((unsigned)tiles, (unsigned)(N / (32 * NBLK))), dim3(256), lds, s, x,
+                     static_cast<const h8*>(Wp), bias, res, y, B, K, N, act);
+}
+// x (B,K,S,S), Wp = the f16x2 weight image for (K -> N) -> y (B,N,S,S)
+void h2_conv(const float* x, const void* Wp, const float* bias, const float* res, float* y, int B, int K, int N, int S, int act,
+             hipStream_t s) {
+  const int nblk = h2_nblk(((long)B * S * S + 127) / 128, N, S);
+#define AFD_H2(S_)                                                                      \
+  if (nblk == 4 && S_ == 16) h2_launch_t<16, 4>(x, Wp, bias, res, y, B, K, N, act, s);  \
+  else if (nblk == 2) h2_launch_t<S_, 2>(x, Wp, bias, res, y, B, K, N, act, s);         \
+  else h2_launch_t<S_, 1>(x, Wp, bias, res, y, B, K, N, act, s)
+  if (S == 32) { AFD_H2(32); } else if (S == 16) { AFD_H2(16); } else { AFD_H2(8); }
+#undef AFD_H2
+}
+
+}  // namespace afd

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "bf3_weights.h"
+#include "h2_common.h"
 
 namespace afd {
 
@@ -114,7 +115,18 @@ __global__ __launch_bounds__(256) void wino_weights_batched(const afd_wino_desc*
   float* wf = (d.kinds & 1) ? nullptr : d.u_fwd; float* wd = (d.kinds & 2) ? nullptr : d.u_dgrad;
   if (wf || wd) wino_weights_block(d.w, wf, wd, d.Cin, d.Cout, blk, lane);
   void* bf = (d.kinds & 1) ? d.u_fwd : nullptr; void* bd = (d.kinds & 2) ? d.u_dgrad : nullptr;
-  if (bf || bd) bf3_weights_block(d.w, static_cast<__bf16*>(bf), static_cast<__bf16*>(bd), d.Cin, d.Cout, blk, lane);   // same wave-per-8x8-block decomposition
+  if (bf || bd) {                                     // the direct form's image: f16x2 (h2.hip) or, kinds bit 2, bf16x3 (bf3.hip); same wave-per-8x8-block decomposition
+    if (d.kinds & 4) bf3_weights_block(d.w, static_cast<__bf16*>(bf), static_cast<__bf16*>(bd), d.Cin, d.Cout, blk, lane);
+    else h2_weights_block(d.w, bf, bd, d.Cin, d.Cout, blk, lane);
+  }
+}
+// the per-row scales of the f16x2 images, one launch ahead of the one above over the same grid: a layer's Cin*Cout/64
+// waves are more than the (Cin + Cout) / 8 row groups it has
+__global__ __launch_bounds__(256) void h2_wscale_batched(const afd_wino_desc* __restrict__ descs, const int* __restrict__ wg_desc) {
+  const afd_wino_desc d = descs[wg_desc[blockIdx.x]];
+  if (d.kinds & 4) return;
+  void* bf = (d.kinds & 1) ? d.u_fwd : nullptr; void* bd = (d.kinds & 2) ? d.u_dgrad : nullptr;
+  if (bf || bd) h2_wscale_rows(d.w, bf, bd, d.Cin, d.Cout, (blockIdx.x - d.first_wg) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 template <int GEO, int BN, int NT>
@@ -556,19 +568,28 @@ static void wino_launch_t(const float* x, const float* U, const float* bias, con
   hipLaunchKernelGGL((conv_wino<GEO, BN, NT>), dim3(grid), dim3(BN * NT / 8), lds, s, x, U, bias, res, y, B, K, N, act, items);
 }
 
-// bf3.hip: the direct bf16x3 form (takes the layers it covers ahead of the Winograd kernels)
+// the direct forms (take the layers they cover ahead of the Winograd kernels): f16x2 (h2.hip, round 3) or bf16x3 (bf3.hip)
 bool bf3_ok(int B, int K, int N, int H, int W);
+bool direct_form_is_bf3();
 void bf3_weights_launch(const float* w, void* Wf, void* Wd, int Cin, int Cout, hipStream_t s);
 void bf3_conv(const float* x, const void* Wp, const float* bias, const float* res, float* y, int B, int K, int N, int S, int act,
               hipStream_t s);
+void h2_weights_launch(const float* w, void* Wf, void* Wd, int Cin, int Cout, hipStream_t s);
+void h2_conv(const float* x, const void* Wp, const float* bias, const float* res, float* y, int B, int K, int N, int S, int act,
+             hipStream_t s);
 
 // conv (dgrad = false: x (B,K,H,W), w (N,K,3,3)) or its input gradient (dgrad = true: x = dY (B,K=Cout,H,W), w (K,N,3,3))
 bool wino_conv(const float* x, const float* w, const float* bias, const float* res, float* y, float* U, int B, int K, int N, int H,
                int W, int act, bool dgrad, bool weights_ready, hipStream_t s) {
   const int Cin = dgrad ? N : K, Cout = dgrad ? K : N;
-  if (U && bf3_ok(B, K, N, H, W)) {                 // the workspace then holds the bf16x3 weight image of this pass
-    if (!weights_ready) bf3_weights_launch(w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout, s);
-    bf3_conv(x, U, bias, res, y, B, K, N, W, act, s);
+  if (U && bf3_ok(B, K, N, H, W)) {                 // the workspace then holds the direct form's weight image of this pass
+    if (direct_form_is_bf3()) {
+      if (!weights_ready) bf3_weights_launch(w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout, s);
+      bf3_conv(x, U, bias, res, y, B, K, N, W, act, s);
+    } else {
+      if (!weights_ready) h2_weights_launch(w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout, s);
+      h2_conv(x, U, bias, res, y, B, K, N, W, act, s);
+    }
     return true;
   }
   const int plan = wino_plan(B, K, N, H, W);
@@ -848,15 +869,20 @@ int wgrad_wino(const float* x, const float* dy, float* part, int B, int Cin, int
   return splits;
 }
 
-// both (or either) transformed-weight images of a layer; kinds bit 0 / 1: the forward / dgrad image is the bf16x3 one
+// both (or either) transformed-weight images of a layer; kinds bit 0 / 1: the forward / dgrad image is the direct form's
+// (f16x2; with bit 2: bf16x3)
 void wino_weights_launch(const float* w, float* Uf, float* Ud, int Cin, int Cout, int kinds, hipStream_t s) {
   float* wf = (kinds & 1) ? nullptr : Uf; float* wd = (kinds & 2) ? nullptr : Ud;
   if (wf || wd) hipLaunchKernelGGL(wino_weights, dim3((unsigned)((Cin * Cout / 64 + 3) / 4)), dim3(256), 0, s, w, wf, wd, Cin, Cout);
   void* bf = (kinds & 1) ? Uf : nullptr; void* bd = (kinds & 2) ? Ud : nullptr;
-  if (bf || bd) bf3_weights_launch(w, bf, bd, Cin, Cout, s);
+  if (bf || bd) {
+    if (kinds & 4) bf3_weights_launch(w, bf, bd, Cin, Cout, s);
+    else h2_weights_launch(w, bf, bd, Cin, Cout, s);
+  }
 }
 
 void wino_weights_batched_launch(const afd_wino_desc* descs, const int* wg_desc, int n_wg, hipStream_t s) {
+  hipLaunchKernelGGL(h2_wscale_batched, dim3((unsigned)n_wg), dim3(256), 0, s, descs, wg_desc);
   hipLaunchKernelGGL(wino_weights_batched, dim3((unsigned)n_wg), dim3(256), 0, s, descs, wg_desc);
 }
 

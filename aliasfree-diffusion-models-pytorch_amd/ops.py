@@ -258,7 +258,10 @@ def flush_wgrads(final=False):
             h = side.cuda_stream
             for fn, keep, ws in items:
                 descs = fn(h) if fn is not None else keep[0]
-                if descs:
+                if descs and G.fold_every == 0:                               # (A/B hook: one fold launch per producer, as in round 2)
+                    fold_now(descs, h)
+                    done.extend(ws)
+                elif descs:
                     G.folds[k].append(descs)
                     G.fold_writes.extend(ws)
                 else:
@@ -266,7 +269,7 @@ def flush_wgrads(final=False):
     G.launched.extend(q)
     G.pending = []
     G.flushes += 1
-    if any(G.folds) and (final or G.flushes >= G.fold_every or (G.fold_hint is not None and G.fold_hint(G.fold_writes + done))):
+    if any(G.folds) and (final or G.flushes >= max(1, G.fold_every) or (G.fold_hint is not None and G.fold_hint(G.fold_writes + done))):
         for k, side in enumerate(sides):
             if G.folds[k]:
                 fold_now(b"".join(G.folds[k]), side.cuda_stream)
@@ -287,7 +290,7 @@ class inplace_param_grads:
         self.prev = (G.inplace, G.side, G.sides, G.on_write, G.fold_hint, G.fold_every)
         ss = self.side_stream
         self.streams = [] if ss is None else (list(ss) if isinstance(ss, (list, tuple)) else [ss])
-        G.inplace, G.batch, G.on_write, G.fold_hint, G.fold_every = True, self.batch, self.on_write, self.fold_hint, max(1, self.fold_every)
+        G.inplace, G.batch, G.on_write, G.fold_hint, G.fold_every = True, self.batch, self.on_write, self.fold_hint, max(0, self.fold_every)
         G.sides, G.side, G.turn = self.streams, (self.streams[0] if self.streams else None), 0
         G.folds, G.fold_writes, G.flushes = [[] for _ in self.streams], [], 0
 
@@ -430,6 +433,12 @@ class GroupNormFiltAct(_Fn):
 # ---------------------------------------------------------------------------------------------
 # F5 / F10 convolution (3x3 pad 1, 1x1)
 # ---------------------------------------------------------------------------------------------
+def _kind_of(kinds, dgrad):
+    """Form of one pass's weight image in an afd_conv3x3_weight_kinds value: 0 = Winograd, 1 = direct f16x2, 5 = direct bf16x3."""
+    direct = kinds >> dgrad & 1
+    return direct | (kinds & 4 if direct else 0)
+
+
 class _WinoWeights:
     """Transformed 3x3 weights (G g G^T, forward and dgrad forms) kept per weight tensor while the weights do not
     change: keyed by the tensor object AND the HIP stream that asks (the transform launch and every kernel reading the
@@ -457,7 +466,7 @@ class _WinoWeights:
             rec[3] = kinds
         capturing = torch.cuda.is_current_stream_capturing()
         key = (id(w), dgrad, _stream())
-        stamp = (w._version, cls.epoch, w.data_ptr(), nbytes, kinds >> dgrad & 1)     # (the image's form follows the batch size)
+        stamp = (w._version, cls.epoch, w.data_ptr(), nbytes, _kind_of(kinds, dgrad))   # (the image's form follows the batch size)
         if not capturing:
             hit = cls.store.get(key)
             if hit is not None and hit[0]() is w and hit[2] == stamp:
@@ -510,7 +519,7 @@ class WinoStepPlan:
 
     def lookup(self, w, nbytes, dgrad, kinds=0):
         e = self.map.get(id(w))
-        if e is None or e[0]() is not w or (e[4] ^ kinds) >> dgrad & 1:       # (another batch size may want the other form)
+        if e is None or e[0]() is not w or _kind_of(e[4], dgrad) != _kind_of(kinds, dgrad):   # (another batch size may want the other form)
             return None
         u = e[3] if dgrad else e[2]
         return u if (u is not None and u.numel() * 4 == nbytes) else None
@@ -537,10 +546,10 @@ def _conv_fwd(x, w, bias, res, y, B, Cin, Cout, H, W, ks, act, want_dgrad=False)
             if not (ready and dready):
                 L.afd_conv3x3_wino_weights(_p(w), _p(u), _p(ud), Cin, Cout, kinds, _stream())
                 ready = 1
-        L.afd_conv3x3_wino_fwd(_p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Cout, H, W, act, _p(u), ready, _stream())
+        L.afd_conv3x3_wino_fwd(_p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Cout, H, W, act, _p(u), ready, kinds, _stream())
     else:
         L.afd_conv_fwd(_p(x), _p(w), _p(bias), _p(res), _p(y), B, Cin, Cout, H, W, ks, act, _stream())
-    return ud
+    return (ud, kinds) if ud is not None else None
 
 
 class Conv(_Fn):
@@ -578,10 +587,11 @@ class Conv(_Fn):
             nb = L.afd_conv3x3_wino_workspace_bytes(B, Cin, Cout, H, W, 1) if ks == 3 else 0
             if nb:
                 if ctx.u_dgrad is not None:            # produced together with the forward image
-                    u, ready = ctx.u_dgrad, 1
+                    (u, kinds), ready = ctx.u_dgrad, 1
                 else:
-                    u, ready = _WinoWeights.get(w, nb, 1, L.afd_conv3x3_weight_kinds(B, Cin, Cout, H, W))
-                L.afd_conv3x3_wino_dgrad(_p(dy), _p(w), _p(dx), _p(dfork), B, Cin, Cout, H, W, _p(u), ready, _stream())
+                    kinds = L.afd_conv3x3_weight_kinds(B, Cin, Cout, H, W)
+                    u, ready = _WinoWeights.get(w, nb, 1, kinds)
+                L.afd_conv3x3_wino_dgrad(_p(dy), _p(w), _p(dx), _p(dfork), B, Cin, Cout, H, W, _p(u), ready, kinds, _stream())
             else:
                 L.afd_conv_dgrad(_p(dy), _p(w), _p(dx), B, Cin, Cout, H, W, ks, _stream())
                 if dfork is not None:                      # (the direct kernels have no add-to-dx epilogue)

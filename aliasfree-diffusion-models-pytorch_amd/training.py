@@ -271,7 +271,7 @@ class TrainStep:
             overlap_wgrad = True
         n_side = int(os.environ.get("AFD_WGRAD_STREAMS", 1))                                # side streams (tuning hook)
         self.wgrad_stream = [torch.cuda.Stream() for _ in range(max(1, n_side))] if overlap_wgrad else None
-        self.wgrad_batch = int(os.environ.get("AFD_WGRAD_BATCH", 16 if graph else 4))      # layers per fork (tuning hook)
+        self.wgrad_batch = 16 if graph else 4                                               # layers per fork (AFD_WGRAD_BATCH overrides, read per step: tuning hook)
         self.opt = FusedAdamW(model, lr=lr)
         want_ddp = distributed if distributed is not None else dist.is_initialized()
         self.ddp = GradAllReduce(self.opt.fp, n_buckets, model=model) if want_ddp else None
@@ -298,7 +298,7 @@ class TrainStep:
             overlap = self.ddp is not None and self.ddp.world > 1 and not self.use_graph      # (a captured backward cannot hold the exchange)
             if overlap:
                 self.ddp.begin_step()                  # bucket all-reduces start during backward, as their gradients complete
-            with ops.inplace_param_grads(self.wgrad_stream, self.wgrad_batch,   # weight gradients add straight into the flat .grad views
+            with ops.inplace_param_grads(self.wgrad_stream, int(os.environ.get("AFD_WGRAD_BATCH", self.wgrad_batch)),   # weight gradients add straight into the flat .grad views
                                          on_write=self.ddp.wrote if overlap else None,
                                          fold_hint=self.ddp.would_complete if overlap else None):
                 loss.backward()

@@ -109,9 +109,10 @@ def kernel_table(dev, B, mode="train"):
 
     def pipe_s(fl, form):
         """Seconds the matrix pipe needs AT PEAK for the multiplies the kernel form issues for `fl` algorithmic flops:
-        bf16x3 = 6 bf16 products per fp32 product on the bf16 MFMA, Winograd = 16/36 of the products on the fp32 MFMA."""
-        return {"bf3": 6.0 * fl / (MFMA_BF16_PEAK_TF * 1e12), "wino": 16.0 / 36.0 * fl / (MFMA_F32_PEAK_TF * 1e12),
-                "direct": fl / (MFMA_F32_PEAK_TF * 1e12)}[form]
+        f16x2 = 3 fp16 products per fp32 product on the fp16 MFMA (same 2500 TFLOP/s dense peak as bf16), bf16x3 = 6 bf16 products,
+        Winograd = 16/36 of the products on the fp32 MFMA."""
+        return {"h2": 3.0 * fl / (MFMA_BF16_PEAK_TF * 1e12), "bf3": 6.0 * fl / (MFMA_BF16_PEAK_TF * 1e12),
+                "wino": 16.0 / 36.0 * fl / (MFMA_F32_PEAK_TF * 1e12), "direct": fl / (MFMA_F32_PEAK_TF * 1e12)}[form]
 
     for (ci, co, S) in CONV3:
         tf, td, tw, ff, fd, fw = cached(seen, (ci, co, S), lambda: conv_layer_times(L, s, dev, B, ci, co, S, fwd_only=not train))
@@ -287,7 +288,7 @@ def kernel_table(dev, B, mode="train"):
             # executed fraction: matrix-pipe time at the peak of the instruction each launch issues / measured time
             row["frac"] = round(r["pipe_s"] / sec, 4)
             row["frac_basis"] = "executed: issued products at the peak of the instruction issued (bf16x3 6x on the 2500 TFLOP/s bf16 MFMA; Winograd 16/36 and direct 1x on the 157.3 TFLOP/s fp32 MFMA)"
-            row["launches_by_form"] = {k: r[k] for k in ("bf3", "wino", "direct") if r.get(k)}
+            row["launches_by_form"] = {k: r[k] for k in ("h2", "bf3", "wino", "direct") if r.get(k)}
             row["frac_algorithmic_vs_fp32_peak"] = round(tf / MFMA_F32_PEAK_TF, 4)
         elif r["bound"] == "mfma":
             row["frac"] = round(tf / MFMA_F32_PEAK_TF, 4)          # attention: algorithmic flops against the fp32 matrix peak
@@ -316,20 +317,20 @@ def conv_layer_times(L, s, dev, B, ci, co, S, reps=5, fwd_only=False):
     kinds = L.afd_conv3x3_weight_kinds(B, ci, co, S, S)
     u = torch.empty(max(nf, nd, 4) // 4, device=dev)
     if nf:
-        tf = ev_time(lambda: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, s), reps)
+        tf = ev_time(lambda: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, kinds, s), reps)
     else:
         tf = ev_time(lambda: L.afd_conv_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 3, 0, s), reps)
-    form = lambda n, bit: "direct" if not n else ("bf3" if kinds & bit else "wino")
+    form = lambda n, bit: "direct" if not n else (("bf3" if kinds & 4 else "h2") if kinds & bit else "wino")
     if fwd_only:
         return tf, 0.0, 0.0, form(nf, 1), None, None
     if ci <= 3:
         td = 0.0
     elif nd:
-        td = ev_time(lambda: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 0, s), reps)
+        td = ev_time(lambda: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 0, kinds, s), reps)
     else:
         td = ev_time(lambda: L.afd_conv_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), B, ci, co, S, S, 3, s), reps)
     tw = ev_time(lambda: L.afd_conv_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, B, ci, co, S, S, 3, 0, ws.data_ptr(), s), reps)
-    return tf, td, tw, form(nf, 1), form(nd, 2), ("direct", "wino", "bf3", "direct")[L.afd_conv_wgrad_form(B, ci, co, S, S, 3)]
+    return tf, td, tw, form(nf, 1), form(nd, 2), ("direct", "wino", "bf3", "direct", "h2")[L.afd_conv_wgrad_form(B, ci, co, S, S, 3)]
 
 
 def pmc_traffic(family, launches, path="profiles/pmc_families.json"):

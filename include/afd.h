@@ -128,7 +128,11 @@ int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, in
  * 96 / 97 / 98 = Winograd form of the 3x3 wgrad chosen by rule (default) / never / whenever the shape is covered;
  * 84 / 85 / 86 = bf16x3 form of the 3x3 wgrad (csrc/bf3_wgrad.hip) by rule (default) / never / whenever the shape is covered
  *                (85 also switches the 1x1 form off); 88 / 89 = bf16x3 form of the 1x1 wgrad by rule (default) / never;
- * 80 / 81 / 82 = bf16x3 form of the 3x3 forward / dgrad (see afd_conv3x3_weight_kinds below);
+ * 80 / 81 / 82 = the DIRECT matrix-core form of the 3x3 forward / dgrad (see afd_conv3x3_weight_kinds below) by the measured
+ *                rule (default) / never / wherever the shape is covered;
+ * 76 / 77 = arithmetic of that direct form: two fp16 pieces under an online power-of-two scale (csrc/h2.hip, default) /
+ *           three bf16 pieces (round 2, csrc/bf3.hip);  78 / 79 = the same choice for the matrix-core 3x3 weight gradient
+ *           (csrc/h2_wgrad.hip / csrc/bf3_wgrad.hip);
  * 92 / 93 = streaming vector kernels for the 1x1 output layer (<= 4 output channels) and its dgrad (csrc/ends.hip) by rule
  *           (default) / never */
 int afd_debug_conv_path(int mode);
@@ -139,7 +143,9 @@ int afd_conv_dgrad(const float* dy, const float* w, float* dx,
 size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ksize);
 /* which kernel afd_conv_wgrad (dbias == NULL) runs for the shape: 0 = direct implicit GEMM on the fp32 MFMA,
  * 1 = Winograd F(3x3,2x2) on the fp32 MFMA, 2 = pixel-reduction GEMM on the bf16 MFMA with exact three-piece splits
- * (fp32 accuracy), 3 = the first layer's vector-FMA form (3 input channels: memory-bound).  For reporting (bench.py prices each launch against the peak of the instruction it issues). */
+ * (fp32 accuracy), 3 = the first layer's vector-FMA form (3 input channels: memory-bound), 4 = the pixel-reduction GEMM on
+ * the fp16 MFMA with two-piece splits under online power-of-two scales (fp32-class accuracy, half the products of 2; the
+ * default since round 3).  For reporting (bench.py prices each launch against the peak of the instruction it issues). */
 int afd_conv_wgrad_form(int B, int Cin, int Cout, int H, int W, int ksize);
 int afd_conv_wgrad(const float* x, const float* dy, float* dw, float* dbias /* or NULL */,
                    int B, int Cin, int Cout, int H, int W, int ksize, int accumulate,
@@ -188,9 +194,13 @@ int afd_conv3x3_wino_weights(const float* w, float* u_fwd, float* u_dgrad, int C
 /* Some layers run a DIRECT form on the bf16 matrix cores at fp32 accuracy instead (csrc/bf3.hip: every operand split
  * exactly into three bf16 pieces, six cross terms per product; chosen by the library per pass from the shape): their
  * workspace holds the split weights (54 bytes per (cin, cout) pair -- the same buffer size serves both forms).
- * kinds: bit 0 / bit 1 set = the forward / the dgrad image of this layer is the bf16x3 one; pass it to the two weight
- * entry points (afd_wino_desc.kinds for the batched one).  afd_debug_conv_path 80 / 81 / 82 = that form by the measured
- * rule (default) / never / wherever the shape is covered. */
+ * kinds: bit 0 / bit 1 set = the forward / the dgrad image of this layer is the DIRECT form's (records of 8 matrix-core
+ * inputs per (piece, tap, channel group, output row)) instead of the Winograd one; bit 2 (only with bit 0 or 1) = that direct
+ * image holds three bf16 pieces (round 2's arithmetic, afd_debug_conv_path 77) instead of two fp16 pieces + one scale per
+ * output row.  The value depends on B (the rule wants >= 2 workgroups per CU) and on afd_debug_conv_path: pass what this
+ * function returned WHEN THE IMAGE WAS BUILT to the two weight entry points (afd_wino_desc.kinds for the batched one) and to
+ * afd_conv3x3_wino_fwd / _dgrad.  afd_debug_conv_path 80 / 81 / 82 = the direct form by the measured rule (default) / never /
+ * wherever the shape is covered. */
 int afd_conv3x3_weight_kinds(int B, int Cin, int Cout, int H, int W);
 /* ... and of EVERY layer of a model in one launch (a train step transforms ~30 weight tensors; one launch instead of
  * 30 takes them off the critical path).  descs (DEVICE array): one entry per layer; wg_desc (DEVICE, n_wg ints): the
@@ -202,12 +212,17 @@ typedef struct afd_wino_desc {
   int Cin, Cout, first_wg, kinds;   /* kinds: afd_conv3x3_weight_kinds of the layer */
 } afd_wino_desc;
 int afd_conv3x3_wino_weights_batched(const afd_wino_desc* descs, const int* wg_desc, int n_wg, afd_stream_t stream);
+/* weights_ready != 0: the workspace already holds the image, built for `kinds` (what afd_conv3x3_weight_kinds returned when
+ * it was built); the call fails with AFD_EINVAL if that is not the form it is about to read (the choice between the forms
+ * depends on the batch size -- e.g. a last partial batch -- and on afd_debug_conv_path).  weights_ready == 0: the image is
+ * built first, in the form this call reads; `kinds` is ignored. */
 int afd_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* res, float* y,
-                         int B, int Cin, int Cout, int H, int W, int act, void* workspace, int weights_ready,
+                         int B, int Cin, int Cout, int H, int W, int act, void* workspace, int weights_ready, int kinds,
                          afd_stream_t stream);
 int afd_conv3x3_wino_dgrad(const float* dy, const float* w, float* dx, const float* add_to_dx /* or NULL: dx = dgrad + add,
                            the gradient that reaches x through the block's residual branch */,
-                           int B, int Cin, int Cout, int H, int W, void* workspace, int weights_ready, afd_stream_t stream);
+                           int B, int Cin, int Cout, int H, int W, void* workspace, int weights_ready, int kinds,
+                           afd_stream_t stream);
 
 /* ---- F10: LayerNorm over channels of an NCHW tensor (= nn.LayerNorm([C]) on (B,L,C) tokens) ------
  * ddpm_utils.py:60,62,70.  stats_out (B,HW,2) = {mean, rstd}. */

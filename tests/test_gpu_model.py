@@ -253,15 +253,15 @@ def test_overlapped_weight_gradients_are_bitwise_equal(A):
     assert torch.equal(outs[1], outs[2])
 
 
-def test_full_batch_step_bf16x3_kernels_agree_with_fp32_kernels(A):
+def test_full_batch_step_matrix_core_kernels_agree_with_fp32_kernels(A):
     """BASELINE size (Config D, B = 256): one forward + backward of the whole net with every layer on the kernels the rule
-    picks (bf16x3 forward / dgrad / 3x3 and 1x1 weight gradients on the matrix cores) against the same step with those
-    switched off (fp32 Winograd / direct kernels, an independent algorithm): loss and every parameter gradient agree far
-    inside the 1e-5 contract.  The rule must really have picked the bf16x3 forms at this size."""
+    picks (f16x2 forward / dgrad / 3x3 weight gradients and bf16x3 1x1 weight gradients on the matrix cores) against the same
+    step with those switched off (fp32 Winograd / direct kernels, an independent algorithm): loss and every parameter
+    gradient agree far inside the 1e-5 contract.  The rule must really have picked the matrix-core forms at this size."""
     afdm, dev = A
     from afdm import ops
     L = afdm.lib()
-    assert L.afd_conv3x3_weight_kinds(256, 128, 128, 16, 16) == 3 and L.afd_conv_wgrad_form(256, 128, 128, 16, 16, 3) == 2
+    assert L.afd_conv3x3_weight_kinds(256, 128, 128, 16, 16) == 3 and L.afd_conv_wgrad_form(256, 128, 128, 16, 16, 3) == 4
     assert L.afd_conv_wgrad_form(256, 32, 96, 32, 32, 1) == 2
     afdm.set_seed(42)
     model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device=dev, variant=3).to(dev)
@@ -291,7 +291,7 @@ def test_full_batch_step_bf16x3_kernels_agree_with_fp32_kernels(A):
         a, b = outs[0][1][n].double(), outs[1][1][n].double()
         if b.norm() > 0:
             worst = max(worst, ((a - b).norm() / b.norm()).item())
-            check("full-batch step: bf16x3 vs fp32 kernels, parameter gradients", outs[0][1][n].cpu(), outs[1][1][n].cpu(), 1e-5, n)
+            check("full-batch step: matrix-core (f16x2 / bf16x3) vs fp32 kernels, parameter gradients", outs[0][1][n].cpu(), outs[1][1][n].cpu(), 1e-5, n)
     assert worst < 1e-5
 
 

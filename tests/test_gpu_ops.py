@@ -362,7 +362,7 @@ def test_conv_full_batch_winograd_vs_direct_and_fp64(A, shape):
         L.afd_debug_conv_path(80)
         L.afd_debug_conv_path(84)
     assert L.afd_conv3x3_wino_workspace_bytes(256, ci, co, S, S, 0) > 0          # the rule really took a transformed-weight kernel
-    assert (L.afd_conv3x3_weight_kinds(256, ci, co, S, S) == 3) == (S >= 8)      # ... the bf16x3 one on the 8x8 and larger maps
+    assert (L.afd_conv3x3_weight_kinds(256, ci, co, S, S) == 3) == (S >= 8)      # ... the direct (f16x2) one on the 8x8 and larger maps
     for leg in ("rule", "wino"):
         for a, b, what in zip(out[leg], out["direct"], ("y", "dx", "dw")):
             assert rel_l2(a.cpu(), b.cpu()) < 3e-6, (leg, what)
@@ -379,6 +379,66 @@ def test_conv_full_batch_winograd_vs_direct_and_fp64(A, shape):
     wd = w.clone().requires_grad_(True)
     (dwd,) = torch.autograd.grad(ops.conv(x[sl].contiguous(), wd), wd, dy[sl].contiguous())
     assert rel_l2(dwd.cpu(), dws) < 1e-5
+
+
+@pytest.mark.parametrize("S,ci,co", [(16, 128, 64), (8, 96, 160), (32, 64, 32)])
+def test_conv_f16x2_online_scaling_dynamic_range(A, S, ci, co):
+    """The direct 3x3 kernels split every operand into two fp16 pieces under a power-of-two scale that follows the data
+    (csrc/h2_common.h): inputs whose 32-channel chunks differ by many orders of magnitude (ascending: the running scale is
+    lowered chunk after chunk and the accumulators rescaled; descending), and tensors near both ends of fp32's range, must
+    come out at the contract's 1e-5 against fp64 -- forward, dgrad (the gradient tensor scaled to 1e-9) and wgrad."""
+    afdm, ops, dev = A
+    L = afdm.lib()
+    B = 6
+    g = _g(S + ci)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)
+    base = torch.randn(B, ci, S, S, generator=g)
+    dy0 = torch.randn(B, co, S, S, generator=g)
+    nch = ci // 32
+    ramps = {"ascending": torch.logspace(-6, 3, nch), "descending": torch.logspace(3, -6, nch), "flat": torch.ones(nch)}
+    for m in (82, 86):                                   # the direct forms wherever the shape is covered (B = 6 is below the rule's size)
+        L.afd_debug_conv_path(m)
+    try:
+        assert L.afd_conv3x3_weight_kinds(B, ci, co, S, S) == 3 and L.afd_conv_wgrad_form(B, ci, co, S, S, 3) in (2, 4)
+        for name, ramp in ramps.items():
+            for gscale, dscale in ((1.0, 1e-9), (1e-25, 1e12), (1e18, 1e-30)):
+                x = base * ramp.repeat_interleave(32)[None, :, None, None] * gscale
+                dy = dy0 * dscale
+                xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+                y = ops.conv(xd, wd)
+                gx, gw = torch.autograd.grad(y, (xd, wd), dy.to(dev))
+                xo, wo = x.double().requires_grad_(True), w.double().requires_grad_(True)
+                yo = F.conv2d(xo, wo, padding=1)
+                gxo, gwo = torch.autograd.grad(yo, (xo, wo), dy.double())
+                tag = (S, ci, co, name, gscale, dscale)
+                check("F5 conv f16x2, wide dynamic range: fwd vs fp64", y.detach().cpu(), yo.detach(), TOL, tag)
+                check("F5 conv f16x2, wide dynamic range: dgrad vs fp64", gx.cpu(), gxo, TOL, tag)
+                check("F5 conv f16x2, wide dynamic range: wgrad vs fp64", gw.cpu(), gwo, TOL, tag)
+    finally:
+        L.afd_debug_conv_path(80)
+        L.afd_debug_conv_path(84)
+
+
+def test_conv_weight_image_form_is_checked(A):
+    """afd_conv3x3_wino_fwd / _dgrad with weights_ready = 1 refuse an image that was built as another form than the one the call
+    reads (the rule depends on the batch size and on the debug switches) instead of multiplying with it."""
+    afdm, ops, dev = A
+    L = afdm.lib()
+    B, ci, co, S = 256, 64, 64, 16
+    x = torch.randn(B, ci, S, S, device=dev); w = torch.randn(co, ci, 3, 3, device=dev) * 0.05; y = torch.empty(B, co, S, S, device=dev)
+    u = torch.empty(L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, 0) // 4, device=dev)
+    kinds = L.afd_conv3x3_weight_kinds(B, ci, co, S, S)
+    assert kinds == 3
+    P = lambda t: t.data_ptr()
+    L.afd_conv3x3_wino_weights(P(w), P(u), None, ci, co, kinds, ops._stream())
+    L.afd_conv3x3_wino_fwd(P(x), P(w), None, None, P(y), B, ci, co, S, S, 0, P(u), 1, kinds, ops._stream())
+    for bad in (0, 7):                                   # a Winograd image / a bf16x3 image handed to a call that reads f16x2
+        with pytest.raises(afdm.AfdError, match="weight image was built as kinds"):
+            L.afd_conv3x3_wino_fwd(P(x), P(w), None, None, P(y), B, ci, co, S, S, 0, P(u), 1, bad, ops._stream())
+    with pytest.raises(afdm.AfdError, match="weight image was built as kinds"):
+        L.afd_conv3x3_wino_dgrad(P(y), P(w), P(x), None, B, ci, co, S, S, P(u), 1, 1, ops._stream())
+    torch.cuda.synchronize()
+    check("F5 conv fwd vs fp64", y[:2].cpu(), F.conv2d(x[:2].cpu().double(), w.cpu().double(), padding=1), TOL, "form-checked call")
 
 
 def test_conv_weight_image_follows_the_batch_size(A):

@@ -39,7 +39,7 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
 
 
 def test_conv_dispatch_rules_are_consistent_on_the_host():
-    """The library's per-shape kernel choice (host code only): the bf16x3 forms take the BASELINE layers by rule, small
+    """The library's per-shape kernel choice (host code only): the matrix-core forms (f16x2; bf16x3 behind switches 77 / 79) take the BASELINE layers by rule, small
     batches and uncovered shapes stay on the fp32 kernels, every chosen form has a workspace to live in, and the debug
     switches turn each form off and on again."""
     import afdm
@@ -51,14 +51,14 @@ def test_conv_dispatch_rules_are_consistent_on_the_host():
             kinds = L.afd_conv3x3_weight_kinds(B, ci, co, S, S)
             assert 0 <= kinds <= 3
             for bit, dgrad in ((1, 0), (2, 1)):
-                if kinds & bit:                                   # a bf16x3 pass keeps its split weights in the shared workspace
-                    assert L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, dgrad) >= 54 * ci * co
+                if kinds & bit:                                   # a direct pass keeps its split weights (+ row scales) in the shared workspace
+                    assert L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, dgrad) >= 54 * ci * co >= 36 * ci * co + 4 * max(ci, co)
             form = L.afd_conv_wgrad_form(B, ci, co, S, S, 3)
-            assert form in (0, 1, 2, 3)
+            assert form in (0, 1, 3, 4)
             assert L.afd_conv_wgrad_workspace_bytes(B, ci, co, S, S, 3) >= 4 * co * ci * 9
     assert L.afd_conv3x3_weight_kinds(256, 128, 128, 16, 16) == 3 and L.afd_conv3x3_weight_kinds(4, 128, 128, 16, 16) == 0
     assert L.afd_conv3x3_weight_kinds(256, 128, 128, 4, 4) == 0 and L.afd_conv3x3_weight_kinds(256, 24, 40, 8, 8) == 0
-    assert L.afd_conv_wgrad_form(256, 128, 128, 16, 16, 3) == 2 and L.afd_conv_wgrad_form(256, 128, 128, 4, 4, 3) == 2
+    assert L.afd_conv_wgrad_form(256, 128, 128, 16, 16, 3) == 4 and L.afd_conv_wgrad_form(256, 128, 128, 4, 4, 3) == 4
     assert L.afd_conv_wgrad_form(256, 3, 32, 32, 32, 3) == 3 and L.afd_conv_wgrad_form(256, 24, 40, 8, 8, 3) == 0
     assert L.afd_conv_wgrad_form(256, 32, 96, 32, 32, 1) == 2 and L.afd_conv_wgrad_form(256, 32, 3, 32, 32, 1) == 0
     try:
@@ -68,8 +68,11 @@ def test_conv_dispatch_rules_are_consistent_on_the_host():
         assert L.afd_conv3x3_wino_workspace_bytes(256, 128, 128, 16, 16, 0) > 0        # the Winograd kernels take over
         L.afd_debug_conv_path(82)
         assert L.afd_conv3x3_weight_kinds(4, 128, 128, 16, 16) == 3                    # forced wherever the shape is covered
+        L.afd_debug_conv_path(77); L.afd_debug_conv_path(79); L.afd_debug_conv_path(84)
+        assert L.afd_conv3x3_weight_kinds(4, 128, 128, 16, 16) == 7                    # ... in round 2's bf16x3 arithmetic
+        assert L.afd_conv_wgrad_form(256, 128, 128, 16, 16, 3) == 2
     finally:
-        L.afd_debug_conv_path(80); L.afd_debug_conv_path(84); L.afd_debug_conv_path(88)
+        L.afd_debug_conv_path(80); L.afd_debug_conv_path(84); L.afd_debug_conv_path(88); L.afd_debug_conv_path(76); L.afd_debug_conv_path(78)
     assert L.afd_conv3x3_weight_kinds(256, 128, 128, 16, 16) == 3
 
 

@@ -20,11 +20,11 @@ for (ci, co, S) in shapes:
         nf = L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, 0); nd = L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, 1)
         r[tag + "f"] = r[tag + "d"] = float("nan")
         if nf:
-            L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, s)
-            r[tag + "f"] = bench.ev_time(lambda: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 1, s), reps=10)
+            L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, L.afd_conv3x3_weight_kinds(B, ci, co, S, S), s)
+            r[tag + "f"] = bench.ev_time(lambda: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 1, L.afd_conv3x3_weight_kinds(B, ci, co, S, S), s), reps=10)
         if nd:
-            L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 0, s)
-            r[tag + "d"] = bench.ev_time(lambda: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 1, s), reps=10)
+            L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 0, L.afd_conv3x3_weight_kinds(B, ci, co, S, S), s)
+            r[tag + "d"] = bench.ev_time(lambda: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 1, L.afd_conv3x3_weight_kinds(B, ci, co, S, S), s), reps=10)
     L.afd_debug_conv_path(80)
     fl = 2.0 * B * S * S * ci * co * 9
     print(f"{ci:4d}->{co:4d} @{S:2d}x{S:<2d} x{cnt}: fwd wino {r['wf']*1e3:7.1f}  bf3 {r['bf']*1e3:7.1f} ({fl/r['bf']/1e9:5.0f} TF)  rule {r['af']*1e3:7.1f} | "

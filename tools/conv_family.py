@@ -26,11 +26,11 @@ for _ in range(reps):
     for (ci, co, S) in bench.CONV3:
         x, w, y, dx, dw, ws, u, nf, nd = bufs[(ci, co, S)]
         if fam == "fwd":
-            if nf: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, s)
+            if nf: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, L.afd_conv3x3_weight_kinds(B, ci, co, S, S), s)
             else: L.afd_conv_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 3, 0, s)
         elif fam == "dgrad":
             if ci <= 3: continue
-            if nd: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 0, s)
+            if nd: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 0, L.afd_conv3x3_weight_kinds(B, ci, co, S, S), s)
             else: L.afd_conv_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), B, ci, co, S, S, 3, s)
         else:
             L.afd_conv_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, B, ci, co, S, S, 3, 0, ws.data_ptr(), s)

@@ -26,8 +26,8 @@ for (ci, co, S) in shapes:
             if dgrad: L.afd_conv_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), B, ci, co, S, S, 3, s)
             else: L.afd_conv_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 3, 0, s)
         def wino():
-            if dgrad: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 0, s)
-            else: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, s)
+            if dgrad: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 0, L.afd_conv3x3_weight_kinds(B, ci, co, S, S), s)
+            else: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, L.afd_conv3x3_weight_kinds(B, ci, co, S, S), s)
         td = bench.ev_time(direct, reps=10)
         ts = []
         for mode in (66, 67, 68, 70, 64):
