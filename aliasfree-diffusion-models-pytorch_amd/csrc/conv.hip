@@ -827,6 +827,7 @@ void wgrad_arith_set(int m);
 bool wgrad_arith_is_bf3();
 // h2_wgrad.hip: the same on the fp16 matrix cores (two-piece splits, online scaling; the plan is shared)
 int wgrad_h2(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
+int pw_wgrad_h2(const float* x, const float* dy, float* part, float* bias_part, int B, int Cin, int Cout, int L, hipStream_t s);
 // ends.hip: the 1x1 output layer and its dgrad as streaming vector kernels
 bool ends_fwd(const float* x, const float* w, const float* bias, const float* res, float* y, int B, int Cin, int Cout, int H, int W,
               int ksize, int act, hipStream_t s);
@@ -1083,7 +1084,7 @@ size_t afd_conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, in
 int afd_conv_wgrad_form(int B, int Cin, int Cout, int H, int W, int ksize) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
   int a, b, c, d;
-  if (ksize == 1) return pw_wgrad_bf3_plan(B, Cin, Cout, H * W, &a, &b, &c, &d) ? 2 : 0;
+  if (ksize == 1) return pw_wgrad_bf3_plan(B, Cin, Cout, H * W, &a, &b, &c, &d) ? (wgrad_arith_is_bf3() ? 2 : 4) : 0;
   if (ksize != 3) return 0;
   if (wgrad_bf3_plan(B, Cin, Cout, H, W, &a, &b)) return wgrad_arith_is_bf3() ? 2 : 4;
   if (wgrad_cin3_plan(B, Cin, Cout, H, W)) return 3;
@@ -1115,7 +1116,8 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dw, float* db
       float* part = static_cast<float*>(workspace);
       const long n = (long)Cout * Cin;
       float* bp = dbias ? part + (size_t)slabs * n : nullptr;
-      pw_wgrad_bf3(x, dy, part, bp, B, Cin, Cout, H * W, s);
+      if (wgrad_arith_is_bf3()) pw_wgrad_bf3(x, dy, part, bp, B, Cin, Cout, H * W, s);
+      else pw_wgrad_h2(x, dy, part, bp, B, Cin, Cout, H * W, s);
       rc = launch_wgrad_reduce(part, dw, n, slabs, bp, dbias, dbias ? Cout : 0, accumulate, 1, s, sink);
       return rc != AFD_OK ? rc : check_launch(who);
     }

@@ -21,7 +21,7 @@ namespace afd {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __global__ __launch_bounds__(256) void h2_wscale(const float* __restrict__ w, void* Wf, void* Wd, int Cin, int Cout) {
-  h2_wscale_rows(w, Wf, Wd, Cin, Cout, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+  h2_wscale_rows(w, Wf, Wd, Cin, Cout, blockIdx.x * 4 + (threadIdx.x >> 6), gridDim.x * 4, threadIdx.x & 63);
 }
 __global__ __launch_bounds__(256) void h2_weights(const float* __restrict__ w, void* Wf, void* Wd, int Cin, int Cout) {
   h2_weights_block(w, Wf, Wd, Cin, Cout, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
@@ -225,8 +225,8 @@ static int h2_nblk(long tiles, int N, int S) {
 }
 
 void h2_weights_launch(const float* w, void* Wf, void* Wd, int Cin, int Cout, hipStream_t s) {
-  const int rows8 = (Wf ? Cout / 8 : 0) + (Wd ? Cin / 8 : 0);
-  hipLaunchKernelGGL(h2_wscale, dim3((unsigned)((rows8 + 3) / 4)), dim3(256), 0, s, w, Wf, Wd, Cin, Cout);
+  const int rows = (Wf ? Cout : 0) + (Wd ? Cin : 0);
+  hipLaunchKernelGGL(h2_wscale, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, w, Wf, Wd, Cin, Cout);
   hipLaunchKernelGGL(h2_weights, dim3((unsigned)((Cin * Cout / 64 + 3) / 4)), dim3(256), 0, s, w, Wf, Wd, Cin, Cout);
 }
 

@@ -78,32 +78,33 @@ __device__ __forceinline__ long h2_rec(int piece, int tap, int k, int n, int K, 
 }
 __host__ __device__ inline size_t h2_scale_offset_bytes(int K, int N) { return (size_t)36 * K * N; }
 
-// phase 1: wave `wi` of a layer owns 8 rows of one image -- rows = output channels of the forward image (wi < Cout / 8) or
-// input channels of the dgrad image -- and writes 1 / s_n of each behind that image.  lane = (row lane >> 3, slice lane & 7).
-__device__ __forceinline__ void h2_wscale_rows(const float* __restrict__ w, void* Wf, void* Wd, int Cin, int Cout, int wi, int lane) {
-  const int nf = Wf ? Cout >> 3 : 0, nd = Wd ? Cin >> 3 : 0;
-  if (wi >= nf + nd) return;
-  const bool fwd = wi < nf;
-  const int r = lane >> 3, j = lane & 7;
-  float m = 0.f;
-  if (fwd) {
-    const int co = wi * 8 + r;
-    const float* p = w + (long)co * Cin * 9;
-    for (int i = j; i < Cin * 9; i += 8) m = fmaxf(m, fabsf(p[i]));
-  } else {
-    const int ci = (wi - nf) * 8 + r;
-    for (int i = j; i < Cout * 9; i += 8) {
-      const int co = i / 9, t = i - co * 9;
-      m = fmaxf(m, fabsf(w[((long)co * Cin + ci) * 9 + t]));
+// phase 1: one wave per ROW of an image -- rows = output channels of the forward image (r < Cout) or input channels of the
+// dgrad image -- the 64 lanes stride over the row's K x 9 weights; wave `wi` of the layer's `nw` takes rows wi, wi + nw, ..
+// and writes 1 / s_n behind the image.
+__device__ __forceinline__ void h2_wscale_rows(const float* __restrict__ w, void* Wf, void* Wd, int Cin, int Cout, int wi, int nw, int lane) {
+  const int nf = Wf ? Cout : 0, nd = Wd ? Cin : 0;
+  for (int r = wi; r < nf + nd; r += nw) {
+    const bool fwd = r < nf;
+    float m0 = 0.f, m1 = 0.f;
+    if (fwd) {
+      const float* p = w + (long)r * Cin * 9;
+      const int n = Cin * 9;
+      int i = lane;
+      for (; i + 64 < n; i += 128) { m0 = fmaxf(m0, fabsf(p[i])); m1 = fmaxf(m1, fabsf(p[i + 64])); }
+      if (i < n) m0 = fmaxf(m0, fabsf(p[i]));
+    } else {
+      const int ci = r - nf, n = Cout * 9;
+      for (int i = lane; i < n; i += 64) {
+        const int co = i / 9, t = i - co * 9;
+        m0 = fmaxf(m0, fabsf(w[((long)co * Cin + ci) * 9 + t]));
+      }
     }
-  }
-  m = fmaxf(m, __shfl_xor(m, 1, kWave));
-  m = fmaxf(m, __shfl_xor(m, 2, kWave));
-  m = fmaxf(m, __shfl_xor(m, 4, kWave));
-  if (j == 0) {
-    const float inv = h2_inv_pow2(h2_scale_for(m));
-    if (fwd) reinterpret_cast<float*>(static_cast<uint8_t*>(Wf) + h2_scale_offset_bytes(Cin, Cout))[wi * 8 + r] = inv;
-    else reinterpret_cast<float*>(static_cast<uint8_t*>(Wd) + h2_scale_offset_bytes(Cout, Cin))[(wi - nf) * 8 + r] = inv;
+    const float m = wave_amax(fmaxf(m0, m1));
+    if (lane == 0) {
+      const float inv = h2_inv_pow2(h2_scale_for(m));
+      if (fwd) reinterpret_cast<float*>(static_cast<uint8_t*>(Wf) + h2_scale_offset_bytes(Cin, Cout))[r] = inv;
+      else reinterpret_cast<float*>(static_cast<uint8_t*>(Wd) + h2_scale_offset_bytes(Cout, Cin))[r - nf] = inv;
+    }
   }
 }
 

@@ -394,6 +394,147 @@ __global__ __launch_bounds__(512, 1) void wgrad_h2_s4(const float* __restrict__ 
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions / token Linear layers:  dW[n][k] = sum_p dY[n][p] X[k][p],  db[n] = sum_p dY[n][p]   (as pw_wgrad_bf3)
+// Both operands come straight from global memory; a wave scales each by its own running power of two (checked per 32-pixel
+// step with ONE compare + ballot per operand: the full wave maximum is only taken when a step would overflow), splits into
+// two fp16 pieces and issues 3 MFMAs per (16 x 16 x 32) block instead of 6.  The bias sums take the unscaled values.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(512, 1) void pw_wgrad_h2(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                      float* __restrict__ bias_part, int B, int K, int N, int L, int steps_per_split,
+                                                      int nsteps, int NR) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kgl = lane >> 4;
+  const int WP = 8 / NR;                                               // pixel slices per workgroup
+  const int role = blockIdx.y * NR + wv % NR, wp = wv / NR;
+  const int ntn = N / (16 * NT);
+  const int n0 = (role % ntn) * 16 * NT, k0 = (role / ntn) * 32;
+  const int split = blockIdx.x;
+  const int sbeg = split * steps_per_split, send = min(nsteps, sbeg + steps_per_split);
+
+  f32x4 acc[NT][2];
+  float bsum[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) { bsum[i] = 0.f; acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+
+  float4 ra[NT][2], rb[2][2];
+  auto fetch = [&](int t) {
+    const long P0 = 32L * t;
+    const long b = P0 / L, p = P0 - b * L + 8 * kgl;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const float4* q = reinterpret_cast<const float4*>(dy + (b * N + n0 + 16 * i + l15) * L + p);
+      ra[i][0] = q[0]; ra[i][1] = q[1];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float4* q = reinterpret_cast<const float4*>(x + (b * K + k0 + 16 * j + l15) * L + p);
+      rb[j][0] = q[0]; rb[j][1] = q[1];
+    }
+  };
+  auto amax8 = [&](const float4& u, const float4& v, float m) {
+    m = fmaxf(fmaxf(m, fabsf(u.x)), fabsf(u.y)); m = fmaxf(fmaxf(m, fabsf(u.z)), fabsf(u.w));
+    m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y)); m = fmaxf(fmaxf(m, fabsf(v.z)), fabsf(v.w));
+    return m;
+  };
+  auto split8 = [&](const float4& u, const float4& v, float s, h8 (&f)[2]) {
+    const float e[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+    h2_split8(e, s, f[0], f[1]);
+  };
+  // lower running scale `s` if this lane-maximum m would leave fp16's range under it (uniform decision by ballot), carrying
+  // the accumulators over; `lim` = 2^15 / s
+  auto fit = [&](float& s, float& lim, float m) {
+    if (__builtin_amdgcn_ballot_w64(!(m < lim)) != 0ull) {              // (rare; also taken for inf / nan)
+      const float sn = fminf(s, h2_scale_for(wave_amax(m)));
+      const float f = sn * h2_inv_pow2(s);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) { acc[i][0] *= f; acc[i][1] *= f; }
+      s = sn; lim = 32768.f * h2_inv_pow2(sn);
+    }
+  };
+  float sa = __uint_as_float(kH2ScaleCapBits), sb = sa, lima = 0.f, limb = 0.f;   // lim = 0: the first step always sets the scales
+  if (sbeg + wp < send) fetch(sbeg + wp);
+#pragma unroll 1
+  for (int t = sbeg + wp; t < send; t += WP) {
+    float ma = 0.f, mb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) ma = amax8(ra[i][0], ra[i][1], ma);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) mb = amax8(rb[j][0], rb[j][1], mb);
+    fit(sa, lima, ma);
+    fit(sb, limb, mb);
+    h8 fa[NT][2], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      split8(ra[i][0], ra[i][1], sa, fa[i]);
+      bsum[i] += ((ra[i][0].x + ra[i][0].y) + (ra[i][0].z + ra[i][0].w)) + ((ra[i][1].x + ra[i][1].y) + (ra[i][1].z + ra[i][1].w));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) split8(rb[j][0], rb[j][1], sb, fb[j]);
+    if (t + WP < send) fetch(t + WP);                                  // in flight during the multiplies
+    constexpr int TA[3] = {0, 1, 0}, TB[3] = {0, 0, 1};
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][TA[m]], fb[j][TB[m]], acc[i][j], 0, 0, 0);
+  }
+  {                                                                    // the true sums (every wave had its own scales)
+    const float ua = h2_inv_pow2(sa), ub = h2_inv_pow2(sb);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { acc[i][0] = (acc[i][0] * ua) * ub; acc[i][1] = (acc[i][1] * ua) * ub; }
+  }
+  // bias: the four pixel groups of a row sit in lanes l15, l15 + 16, + 32, + 48
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    bsum[i] += __shfl_xor(bsum[i], 16, kWave);
+    bsum[i] += __shfl_xor(bsum[i], 32, kWave);
+  }
+  // pixel slices 1 .. WP-1 hand their sums to slice 0 through LDS, in a fixed order
+  float* red = reinterpret_cast<float*>(smem_raw);                    // [role in workgroup][NT * 8 + NT][64]
+  const int rl = wv % NR;
+#pragma unroll 1
+  for (int g = 1; g < WP; ++g) {
+    __syncthreads();
+    if (wp == g) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) red[(rl * (NT * 9) + (i * 2 + j) * 4 + rg) * 64 + lane] = acc[i][j][rg];
+        red[(rl * (NT * 9) + NT * 8 + i) * 64 + lane] = bsum[i];
+      }
+    }
+    __syncthreads();
+    if (wp == 0) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) acc[i][j][rg] += red[(rl * (NT * 9) + (i * 2 + j) * 4 + rg) * 64 + lane];
+        bsum[i] += red[(rl * (NT * 9) + NT * 8 + i) * 64 + lane];
+      }
+    }
+  }
+  if (wp != 0) return;
+  float* ps = part + (long)split * N * K;
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) ps[(long)(n0 + 16 * i + 4 * kgl + rg) * K + k0 + 16 * j + l15] = acc[i][j][rg];
+  if (bias_part && k0 == 0 && kgl == 0) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) bias_part[(long)split * N + n0 + 16 * i + l15] = bsum[i];
+  }
+}
+
 // ---- host side (the plan -- tiles per split, block sizes -- is bf3_wgrad.hip's) ---------------------------------------------
 int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles);
 void wgrad_bf3_tile_for(int Cin, int Cout, long nt, int* bn, int* bk);
@@ -445,6 +586,20 @@ int wgrad_h2(const float* x, const float* dy, float* part, int B, int Cin, int C
   else if (k64) wgrad_h2_s4_launch_t<32, 64>(x, dy, part, B, Cin, Cout, tps, nt, splits, s);
   else wgrad_h2_s4_launch_t<32, 32>(x, dy, part, B, Cin, Cout, tps, nt, splits, s);
 #undef AFD_WGH
+  return splits;
+}
+
+
+int pw_wgrad_bf3_plan(int B, int Cin, int Cout, int L, int* sps, int* nsteps, int* nr, int* nt);
+int pw_wgrad_h2(const float* x, const float* dy, float* part, float* bias_part, int B, int Cin, int Cout, int L, hipStream_t s) {
+  int sps, st, NR, NT;
+  const int splits = pw_wgrad_bf3_plan(B, Cin, Cout, L, &sps, &st, &NR, &NT);
+  if (!splits) return 0;
+  const int roles = (Cout / (16 * NT)) * (Cin / 32);
+  const size_t lds = 8 / NR > 1 ? sizeof(float) * NR * NT * 9 * 64 : 0;
+  const dim3 grid((unsigned)splits, (unsigned)(roles / NR));
+  if (NT == 3) hipLaunchKernelGGL(pw_wgrad_h2<3>, grid, dim3(512), lds, s, x, dy, part, bias_part, B, Cin, Cout, L, sps, st, NR);
+  else hipLaunchKernelGGL(pw_wgrad_h2<2>, grid, dim3(512), lds, s, x, dy, part, bias_part, B, Cin, Cout, L, sps, st, NR);
   return splits;
 }
 

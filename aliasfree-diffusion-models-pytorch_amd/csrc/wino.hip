@@ -121,12 +121,13 @@ __global__ __launch_bounds__(256) void wino_weights_batched(const afd_wino_desc*
   }
 }
 // the per-row scales of the f16x2 images, one launch ahead of the one above over the same grid: a layer's Cin*Cout/64
-// waves are more than the (Cin + Cout) / 8 row groups it has
+// waves share its Cin + Cout rows (one wave per row on the wide layers)
 __global__ __launch_bounds__(256) void h2_wscale_batched(const afd_wino_desc* __restrict__ descs, const int* __restrict__ wg_desc) {
   const afd_wino_desc d = descs[wg_desc[blockIdx.x]];
   if (d.kinds & 4) return;
   void* bf = (d.kinds & 1) ? d.u_fwd : nullptr; void* bd = (d.kinds & 2) ? d.u_dgrad : nullptr;
-  if (bf || bd) h2_wscale_rows(d.w, bf, bd, d.Cin, d.Cout, (blockIdx.x - d.first_wg) * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+  const int nw = 4 * ((d.Cin * d.Cout / 64 + 3) / 4);                  // the waves this layer owns in the grid (afd_wino_desc: ceil(Cin*Cout/256) workgroups)
+  if (bf || bd) h2_wscale_rows(d.w, bf, bd, d.Cin, d.Cout, (blockIdx.x - d.first_wg) * 4 + (threadIdx.x >> 6), nw, threadIdx.x & 63);
 }
 
 template <int GEO, int BN, int NT>

@@ -123,6 +123,17 @@ def kernel_table(dev, B, mode="train"):
         if ci > 3:
             add("conv3x3_dgrad", td, fl, bound="mfma", pipe_s=pipe_s(fl, fd), **{fd: 1})
         add("conv3x3_wgrad", tw, fl, bound="mfma", pipe_s=pipe_s(fl, fw), **{fw: 1})
+    if train:
+        # the weight images of all 3x3 layers (row scales + two-piece splits, or the Winograd transform): ONE batched call at the
+        # start of every step (ops.WinoStepPlan); sampling builds them once per trajectory
+        reqs = {}
+        for i, (ci, co, S) in enumerate(CONV3):
+            nf, nd = L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, 0), L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, 1)
+            if nf or nd:
+                reqs[i] = [torch.randn(co, ci, 3, 3, device=dev) * 0.05, nf, nd, L.afd_conv3x3_weight_kinds(B, ci, co, S, S)]
+        plan = ops.WinoStepPlan(reqs)
+        add("conv3x3_weight_images", ev_time(plan.launch), bytes_=sum(4.0 * 9 * r[0].shape[0] * r[0].shape[1] + r[1] + r[2] for r in reqs.values()),
+            launches=2, bound="hbm")
     # ---- filtered GELU (F4) + the GroupNorm kernels around it (F6) ------------------------------------------------
     seen = {}
     tk = ops.Taps(afdm.circularLowpassKernel(math.pi / 2, 3, 2))
@@ -316,8 +327,11 @@ def conv_layer_times(L, s, dev, B, ci, co, S, reps=5, fwd_only=False):
     nf, nd = L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, 0), L.afd_conv3x3_wino_workspace_bytes(B, ci, co, S, S, 1)
     kinds = L.afd_conv3x3_weight_kinds(B, ci, co, S, S)
     u = torch.empty(max(nf, nd, 4) // 4, device=dev)
+    # (weights_ready = 1 in the timed calls: a step builds every layer's weight image in ONE batched launch at its start,
+    # ops.WinoStepPlan; sampling builds them once per trajectory)
     if nf:
-        tf = ev_time(lambda: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, kinds, s), reps)
+        L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, kinds, s)
+        tf = ev_time(lambda: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 1, kinds, s), reps)
     else:
         tf = ev_time(lambda: L.afd_conv_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 3, 0, s), reps)
     form = lambda n, bit: "direct" if not n else (("bf3" if kinds & 4 else "h2") if kinds & bit else "wino")
@@ -326,7 +340,8 @@ def conv_layer_times(L, s, dev, B, ci, co, S, reps=5, fwd_only=False):
     if ci <= 3:
         td = 0.0
     elif nd:
-        td = ev_time(lambda: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 0, kinds, s), reps)
+        L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 0, kinds, s)
+        td = ev_time(lambda: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 1, kinds, s), reps)
     else:
         td = ev_time(lambda: L.afd_conv_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), B, ci, co, S, S, 3, s), reps)
     tw = ev_time(lambda: L.afd_conv_wgrad(x.data_ptr(), y.data_ptr(), dw.data_ptr(), None, B, ci, co, S, S, 3, 0, ws.data_ptr(), s), reps)

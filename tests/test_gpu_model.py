@@ -262,7 +262,7 @@ def test_full_batch_step_matrix_core_kernels_agree_with_fp32_kernels(A):
     from afdm import ops
     L = afdm.lib()
     assert L.afd_conv3x3_weight_kinds(256, 128, 128, 16, 16) == 3 and L.afd_conv_wgrad_form(256, 128, 128, 16, 16, 3) == 4
-    assert L.afd_conv_wgrad_form(256, 32, 96, 32, 32, 1) == 2
+    assert L.afd_conv_wgrad_form(256, 32, 96, 32, 32, 1) == 4
     afdm.set_seed(42)
     model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device=dev, variant=3).to(dev)
     diff = afdm.Diffusion(noise_steps=1000, img_size=32, device=dev)

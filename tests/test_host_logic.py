@@ -60,7 +60,7 @@ def test_conv_dispatch_rules_are_consistent_on_the_host():
     assert L.afd_conv3x3_weight_kinds(256, 128, 128, 4, 4) == 0 and L.afd_conv3x3_weight_kinds(256, 24, 40, 8, 8) == 0
     assert L.afd_conv_wgrad_form(256, 128, 128, 16, 16, 3) == 4 and L.afd_conv_wgrad_form(256, 128, 128, 4, 4, 3) == 4
     assert L.afd_conv_wgrad_form(256, 3, 32, 32, 32, 3) == 3 and L.afd_conv_wgrad_form(256, 24, 40, 8, 8, 3) == 0
-    assert L.afd_conv_wgrad_form(256, 32, 96, 32, 32, 1) == 2 and L.afd_conv_wgrad_form(256, 32, 3, 32, 32, 1) == 0
+    assert L.afd_conv_wgrad_form(256, 32, 96, 32, 32, 1) == 4 and L.afd_conv_wgrad_form(256, 32, 3, 32, 32, 1) == 0
     try:
         L.afd_debug_conv_path(81); L.afd_debug_conv_path(85)
         assert L.afd_conv3x3_weight_kinds(256, 128, 128, 16, 16) == 0
