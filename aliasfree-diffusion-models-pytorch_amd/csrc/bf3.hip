@@ -232,19 +232,28 @@ static int bf3_nblk(long tiles, int N, int S) {
   return 1;
 }
 
-// does the bf16x3 direct kernel take the layer (reduction width K, N output channels)?
-bool bf3_ok(int B, int K, int N, int H, int W) {
-  if (g_bf3_mode == 1) return false;
-  // (4 x 4 maps: the same kernel with 8 images per tile was measured -- 32 tiles x N / 32 = 128-256 workgroups of one wave per
-  // SIMD: 20 / 41 us for 128->128 / 256->256 against the split-K Winograd kernel's 11 / 28 -- and is not instantiated)
-  if (H != W || (W != 8 && W != 16 && W != 32)) return false;
-  if (K % 32 || N % 32 || K < 32) return false;
-  if ((long)B * K * H * W >= (1L << 31) || (long)B * N * H * W >= (1L << 31)) return false;
-  if (g_bf3_mode == 2) return true;
+// does a direct matrix-core kernel take the layer (reduction width K, N output channels)?  0 = no, 1 = the 128-pixel tile
+// kernel (conv_h2 / conv_bf3), 2 = the split-K small-map kernel (conv_h2_sk: f16x2 arithmetic only; afd_debug_conv_path 74 / 75
+// = by this rule (default) / never)
+bool h2_sk_ok(int B, int K, int N, int H, int W, bool force);          // h2.hip
+static int g_sk_mode = 0;           // afd_debug_conv_path 74 / 75 / 73: by the rule / never / wherever the shape is covered (ahead of the tile kernel)
+void h2_sk_set_mode(int m) { g_sk_mode = m; }
+int direct_plan(int B, int K, int N, int H, int W) {
+  if (g_bf3_mode == 1) return 0;
+  if (!g_direct_bf3 && g_sk_mode == 2 && h2_sk_ok(B, K, N, H, W, true)) return 2;
+  const bool sk = !g_direct_bf3 && g_sk_mode != 1 && h2_sk_ok(B, K, N, H, W, g_bf3_mode == 2);
+  // (4 x 4 maps on the tile kernel: 8 images per tile, 32 tiles x N / 32 = 128-256 workgroups of one wave per SIMD: measured
+  // 20 / 41 us for 128->128 / 256->256 in round 2 -- not instantiated; the split-K kernel takes them)
+  if (H != W || (W != 8 && W != 16 && W != 32)) return sk ? 2 : 0;
+  if (K % 32 || N % 32 || K < 32) return 0;
+  if ((long)B * K * H * W >= (1L << 31) || (long)B * N * H * W >= (1L << 31)) return 0;
+  if (g_bf3_mode == 2) return 1;
   const long tiles = ((long)B * H * W + 127) / 128;
   const int nblk = bf3_nblk(tiles, N, W);
-  return tiles * (N / (32 * nblk)) >= 512;                            // two workgroups per CU (measured: below that the Winograd / split-K forms win)
+  if (tiles * (N / (32 * nblk)) >= 512) return 1;                     // two workgroups per CU (measured: below that the small-map forms win)
+  return sk ? 2 : 0;
 }
+bool bf3_ok(int B, int K, int N, int H, int W) { return direct_plan(B, K, N, H, W) != 0; }
 size_t bf3_weight_bytes(int Cin, int Cout) { return (size_t)54 * Cin * Cout; }
 
 void bf3_weights_launch(const float* w, void* Wf, void* Wd, int Cin, int Cout, hipStream_t s) {

@@ -216,6 +216,179 @@ __global__ __launch_bounds__(256, 2) void conv_h2(const float* __restrict__ x, c
   }
 }
 
+// ---- the small maps (4 x 4, thin 8 x 8 layers): in-workgroup split-K ------------------------------------------------------
+// At B = 256 a 4 x 4 map has 4096 pixels: 32 tiles of 128, too few workgroups for the kernel above (one wave per SIMD, every
+// wave walking all of K: 20-40 us for a few GFLOP).  Here a workgroup owns 32 output channels x PSP slices of 32 pixels (two
+// 4 x 4 images, or four rows of an 8 x 8 image: every halo cell outside the slice's rows is another slice's pixel or zero
+// padding) and its four waves are KSP K-slices x PSP pixel slices that never meet in the loop: wave-private LDS image of its
+// chunk, its own running scale, no barrier; the KSP partial sums are unscaled and added in wave order through LDS once, at
+// the end.  Replaces round 1's fp32 Winograd split-K kernel (conv_wino_sk) wherever the f16x2 arithmetic is on.
+template <int S> struct SkGeo {
+  static constexpr int IPS = S == 4 ? 2 : 1;                          // images per 32-pixel slice
+  static constexpr int R = 32 / (IPS * S);                            // rows per image in the slice (4 x 4: 4, 8 x 8: 4)
+  static constexpr int Wp = S + 2, IMG = (R + 2) * Wp, NPIX = IPS * IMG, NPP = (NPIX + 15) / 16 * 16;
+  static constexpr int KG = 4, TASKS = KG * NPIX, NE = (TASKS + 63) / 64;
+};
+
+template <int S, int KSP>
+__global__ __launch_bounds__(256, 2) void conv_h2_sk(const float* __restrict__ x, const h8* __restrict__ Wp,
+                                                     const float* __restrict__ bias, const float* __restrict__ res,
+                                                     float* __restrict__ y, int B, int K, int N, int act, int nslices) {
+  using G = SkGeo<S>;
+  constexpr int PSP = 4 / KSP, NPP = G::NPP, NE = G::NE, HW = S * S;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kgl = lane >> 4, l15 = lane & 15;
+  const int kw = wv % KSP, pw = wv / KSP;
+  h8* Xw = reinterpret_cast<h8*>(smem_raw) + (size_t)wv * 2 * G::KG * NPP;     // this wave's [piece 2][kg 4][NPP] records
+  float* red = reinterpret_cast<float*>(smem_raw + (size_t)4 * 2 * G::KG * NPP * 16);   // [wave][16][64] partial sums
+  const int sl = blockIdx.x * PSP + pw, n0 = blockIdx.y * 32;
+  const bool live = sl < nslices;
+  const int img0 = S == 4 ? sl * 2 : sl / 2, row0 = S == 4 ? 0 : (sl & 1) * 4;
+
+  int s_src[NE], s_dst[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int t = lane + 64 * e;
+    s_src[e] = -1; s_dst[e] = -1;
+    if (t < G::TASKS) {
+      const int kg = t / G::NPIX, ridx = t - kg * G::NPIX;
+      const int i = ridx / G::IMG, rem = ridx - i * G::IMG, rr = rem / G::Wp, cc = rem - rr * G::Wp;
+      const int yy = row0 + rr - 1, xx = cc - 1, b = img0 + i;
+      s_dst[e] = kg * NPP + ridx;
+      if (live && yy >= 0 && yy < S && xx >= 0 && xx < S && b < B) s_src[e] = ((i * K + 8 * kg) * S + yy) * S + xx;
+    }
+  }
+  const float* xb = x + (long)(live ? img0 : 0) * K * HW;
+  float xr[NE][8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const float* p = xb + (long)k0 * HW + (s_src[e] >= 0 ? s_src[e] : 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xr[e][j] = s_src[e] >= 0 ? p[(long)j * HW] : 0.f;
+    }
+  };
+  int bbase[2];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int q = ps * 16 + l15;
+    const int i = q / (G::R * S), rem = q - i * (G::R * S), r = rem / S, c = rem - r * S;
+    bbase[ps] = kgl * NPP + i * G::IMG + r * G::Wp + c;
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) acc[ns][ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int KS = K >> 5;
+  const long pstride = (long)9 * (K >> 3) * N;
+  const h8* wl = Wp + (long)kgl * N + n0 + l15;
+  float sx = __uint_as_float(kH2ScaleCapBits);
+  if (kw < KS) fetch(32 * kw);
+  for (int ks = kw; ks < KS; ks += KSP) {
+    // A fragments, three taps (one filter row) at a time, one row ahead of the multiplies; the first row is requested
+    // before the LDS round trip of the staging
+    h8 ac[3][2][2], an[3][2][2];
+    auto a_row = [&](h8 (&a)[3][2][2], int ty) {
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const long r = ((long)(ty * 3 + tx) * (K >> 3) + 4 * ks) * N;
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns) { a[tx][ns][0] = wl[r + 16 * ns]; a[tx][ns][1] = wl[pstride + r + 16 * ns]; }
+      }
+    };
+    a_row(ac, 0);
+    {                                                                 // the chunk's magnitude -> this wave's scale (no one else reads it)
+      float m = 0.f;
+#pragma unroll
+      for (int e = 0; e < NE; ++e)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(xr[e][j]));
+      const float sn = fminf(sx, h2_scale_for(wave_amax(m)));
+      if (sn != sx) {
+        const float f = sn * h2_inv_pow2(sx);
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps) acc[ns][ps] *= f;
+        sx = sn;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      if (s_dst[e] < 0) continue;
+      h8 p0, p1;
+      h2_split8(xr[e], sx, p0, p1);
+      Xw[s_dst[e]] = p0;
+      Xw[G::KG * NPP + s_dst[e]] = p1;
+    }
+    if (ks + KSP < KS) fetch(32 * (ks + KSP));                        // the wave's next chunk in flight during the multiplies
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      if (ty < 2) a_row(an, ty + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int o = bbase[ps] + ty * G::Wp + tx;
+          const h8 b0 = Xw[o], b1 = Xw[G::KG * NPP + o];
+#pragma unroll
+          for (int ns = 0; ns < 2; ++ns) {
+            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ac[tx][ns][0], b0, acc[ns][ps], 0, 0, 0);
+            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ac[tx][ns][1], b0, acc[ns][ps], 0, 0, 0);
+            acc[ns][ps] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ac[tx][ns][0], b1, acc[ns][ps], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ty < 2) {
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+          for (int ns = 0; ns < 2; ++ns) { ac[tx][ns][0] = an[tx][ns][0]; ac[tx][ns][1] = an[tx][ns][1]; }
+      }
+    }
+  }
+  // ---- the K-slices' partial sums: unscaled (each wave had its own scale), added in wave order
+  {
+    const float isx = h2_inv_pow2(sx);
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) red[(wv * 16 + (ns * 2 + ps) * 4 + rg) * 64 + lane] = acc[ns][ps][rg] * isx;
+  }
+  __syncthreads();
+  if (kw != 0 || !live) return;
+  const float* isw = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(Wp) + h2_scale_offset_bytes(K, N));
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int q = ps * 16 + l15;
+    const int i = q / (G::R * S), rem = q - i * (G::R * S), r = rem / S, c = rem - r * S;
+    const int b = img0 + i;
+    if (b >= B) continue;
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns) {
+      const int nn = n0 + 16 * ns + 4 * kgl;
+      const long o = ((long)b * N + nn) * HW + (row0 + r) * S + c;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < KSP; ++g) v += red[((pw * KSP + g) * 16 + (ns * 2 + ps) * 4 + rg) * 64 + lane];
+        v *= isw[nn + rg];
+        if (bias) v += bias[nn + rg];
+        if (act == 1) v = gelu_erf(v);
+        if (res) v += res[o + (long)rg * HW];
+        y[o + (long)rg * HW] = v;
+      }
+    }
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------
 // channel blocks per workgroup: as bf3.hip (as many as divide N while the launch keeps two workgroups per CU)
 static int h2_nblk(long tiles, int N, int S) {
@@ -239,9 +412,33 @@ static void h2_launch_t(const float* x, const void* Wp, const float* bias, const
   hipLaunchKernelGGL((conv_h2<S, NBLK>), dim3((unsigned)tiles, (unsigned)(N / (32 * NBLK))), dim3(256), lds, s, x,
                      static_cast<const h8*>(Wp), bias, res, y, B, K, N, act);
 }
+template <int S, int KSP>
+static void h2_sk_launch_t(const float* x, const void* Wp, const float* bias, const float* res, float* y, int B, int K, int N, int act,
+                           hipStream_t s) {
+  using G = SkGeo<S>;
+  const size_t lds = (size_t)4 * 2 * G::KG * G::NPP * 16 + sizeof(float) * 4 * 16 * 64;
+  const int nslices = (int)(((long)B * S * S + 31) / 32), psp = 4 / KSP;
+  hipLaunchKernelGGL((conv_h2_sk<S, KSP>), dim3((unsigned)((nslices + psp - 1) / psp), (unsigned)(N / 32)), dim3(256), lds, s, x,
+                     static_cast<const h8*>(Wp), bias, res, y, B, K, N, act, nslices);
+}
+// does the split-K small-map kernel take the layer?  4 x 4 and 8 x 8 maps, 32-channel blocks, at least two chunks of K, and a
+// launch that the tile kernel above cannot fill (its rule: >= 512 workgroups) but this one can (>= 128)
+bool h2_sk_ok(int B, int K, int N, int H, int W, bool force) {
+  if (H != W || (W != 4 && W != 8) || K % 32 || N % 32 || K < 64) return false;
+  if ((long)B * K * H * W >= (1L << 31) || (long)B * N * H * W >= (1L << 31)) return false;
+  if (force) return true;
+  const long slices = ((long)B * H * W + 31) / 32;
+  const int ksp = K >= 128 ? 4 : 2;
+  return ((slices + 4 / ksp - 1) / (4 / ksp)) * (N / 32) >= 128;
+}
 // x (B,K,S,S), Wp = the f16x2 weight image for (K -> N) -> y (B,N,S,S)
 void h2_conv(const float* x, const void* Wp, const float* bias, const float* res, float* y, int B, int K, int N, int S, int act,
-             hipStream_t s) {
+             hipStream_t s, bool small) {
+  if (small) {
+    if (S == 4) { if (K >= 128) h2_sk_launch_t<4, 4>(x, Wp, bias, res, y, B, K, N, act, s); else h2_sk_launch_t<4, 2>(x, Wp, bias, res, y, B, K, N, act, s); }
+    else { if (K >= 128) h2_sk_launch_t<8, 4>(x, Wp, bias, res, y, B, K, N, act, s); else h2_sk_launch_t<8, 2>(x, Wp, bias, res, y, B, K, N, act, s); }
+    return;
+  }
   const int nblk = h2_nblk(((long)B * S * S + 127) / 128, N, S);
 #define AFD_H2(S_)                                                                      \
   if (nblk == 4 && S_ == 16) h2_launch_t<16, 4>(x, Wp, bias, res, y, B, K, N, act, s);  \

@@ -577,7 +577,8 @@ void bf3_conv(const float* x, const void* Wp, const float* bias, const float* re
               hipStream_t s);
 void h2_weights_launch(const float* w, void* Wf, void* Wd, int Cin, int Cout, hipStream_t s);
 void h2_conv(const float* x, const void* Wp, const float* bias, const float* res, float* y, int B, int K, int N, int S, int act,
-             hipStream_t s);
+             hipStream_t s, bool small);
+int direct_plan(int B, int K, int N, int H, int W);
 
 // conv (dgrad = false: x (B,K,H,W), w (N,K,3,3)) or its input gradient (dgrad = true: x = dY (B,K=Cout,H,W), w (K,N,3,3))
 bool wino_conv(const float* x, const float* w, const float* bias, const float* res, float* y, float* U, int B, int K, int N, int H,
@@ -589,7 +590,7 @@ bool wino_conv(const float* x, const float* w, const float* bias, const float* r
       bf3_conv(x, U, bias, res, y, B, K, N, W, act, s);
     } else {
       if (!weights_ready) h2_weights_launch(w, dgrad ? nullptr : U, dgrad ? U : nullptr, Cin, Cout, s);
-      h2_conv(x, U, bias, res, y, B, K, N, W, act, s);
+      h2_conv(x, U, bias, res, y, B, K, N, W, act, s, direct_plan(B, K, N, H, W) == 2);
     }
     return true;
   }

@@ -130,6 +130,9 @@ int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, in
  *                (85 also switches the 1x1 form off); 88 / 89 = bf16x3 form of the 1x1 wgrad by rule (default) / never;
  * 80 / 81 / 82 = the DIRECT matrix-core form of the 3x3 forward / dgrad (see afd_conv3x3_weight_kinds below) by the measured
  *                rule (default) / never / wherever the shape is covered;
+ * 74 / 75 = the f16x2 split-K kernel for the 4x4 maps and the thin 8x8 launches (csrc/h2.hip conv_h2_sk; also a direct form:
+ *           afd_conv3x3_weight_kinds reports it) by rule (default) / never (round 1's fp32 Winograd split-K kernel instead);
+ *           73 = wherever the shape is covered, ahead of the tile kernel (tests);
  * 76 / 77 = arithmetic of that direct form: two fp16 pieces under an online power-of-two scale (csrc/h2.hip, default) /
  *           three bf16 pieces (round 2, csrc/bf3.hip);  78 / 79 = the same choice for the matrix-core 3x3 weight gradient
  *           (csrc/h2_wgrad.hip / csrc/bf3_wgrad.hip);

@@ -258,19 +258,20 @@ CONV_CASES = [
     (5, 128, 64, 8, 8, 3, False, False),      # Winograd: four images per tile group, ragged last group
     (2, 64, 32, 16, 16, 3, True, True),       # Winograd epilogue: bias + residual (+ GELU in the no-grad form)
     (3, 8, 96, 16, 16, 3, False, False),      # Winograd: one chunk, three 32-channel blocks
-    (6, 64, 96, 4, 4, 3, True, True),         # small-map split-K Winograd: 4 images per group, ragged last group, epilogue
-    (3, 128, 32, 8, 8, 3, False, False),      # small-map split-K Winograd: one 8x8 image per group
+    (6, 64, 96, 4, 4, 3, True, True),         # small-map split-K kernels (Winograd / f16x2): ragged last group, epilogue; f16x2: K = 64 -> 2 K-slices x 2 pixel slices
+    (3, 128, 32, 8, 8, 3, False, False),      # small-map split-K kernels: one 8x8 image per group; f16x2: 4 K-slices, odd image count
+    (7, 256, 64, 4, 4, 3, False, False),      # f16x2 split-K: 8 chunks over 4 waves, odd image count (a half-empty last slice)
     (3, 32, 128, 32, 32, 3, True, True),      # direct bf16x3 form: four 32-channel blocks per workgroup, epilogue
     (5, 256, 256, 8, 8, 3, False, False),     # direct bf16x3 form: 8 chunks, two images per tile, ragged last tile
     (2, 96, 160, 16, 16, 3, False, False),    # direct bf16x3 form: 3 chunks, five single 32-channel blocks
 ]
 
 
-@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "bf3", "nobf3", "wgbf3", "nowgbf3", "noends", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "winosk", "nowino", "wgwino", "nowgwino"])
+@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "bf3", "nobf3", "h2sk", "wgbf3", "nowgbf3", "noends", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "winosk", "nowino", "wgwino", "nowgwino"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[5]}" for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(A, case, path):
     afdm, ops, dev = A
-    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10, "bf3": 82, "nobf3": 81, "wgbf3": 86, "nowgbf3": 85, "noends": 93,
+    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10, "bf3": 82, "nobf3": 81, "h2sk": 73, "wgbf3": 86, "nowgbf3": 85, "noends": 93,
                                         "wino64x64": 66, "wino32x64": 67, "wino64x32": 68, "wino32x32": 69, "winosk": 70, "nowino": 65, "wgwino": 98, "nowgwino": 97}[path])
     try:
         _conv_case(ops, dev, case)
@@ -279,6 +280,7 @@ def test_conv_fwd_dgrad_wgrad(A, case, path):
         afdm.lib().afd_debug_conv_path(34)
         afdm.lib().afd_debug_conv_path(8)
         afdm.lib().afd_debug_conv_path(80)
+        afdm.lib().afd_debug_conv_path(74)
         afdm.lib().afd_debug_conv_path(84)
         afdm.lib().afd_debug_conv_path(92)
         afdm.lib().afd_debug_conv_path(64)
@@ -362,7 +364,7 @@ def test_conv_full_batch_winograd_vs_direct_and_fp64(A, shape):
         L.afd_debug_conv_path(80)
         L.afd_debug_conv_path(84)
     assert L.afd_conv3x3_wino_workspace_bytes(256, ci, co, S, S, 0) > 0          # the rule really took a transformed-weight kernel
-    assert (L.afd_conv3x3_weight_kinds(256, ci, co, S, S) == 3) == (S >= 8)      # ... the direct (f16x2) one on the 8x8 and larger maps
+    assert L.afd_conv3x3_weight_kinds(256, ci, co, S, S) == 3                    # ... a direct (f16x2) one: the tile kernel, or the split-K kernel on the 4x4 maps
     for leg in ("rule", "wino"):
         for a, b, what in zip(out[leg], out["direct"], ("y", "dx", "dw")):
             assert rel_l2(a.cpu(), b.cpu()) < 3e-6, (leg, what)

@@ -39,3 +39,36 @@ for (ci, co, S) in shapes:
             tot[k] += cnt * r[k]
 print("per step (ms), direct-form layers only: fwd bf16x3 %.3f f16x2 %.3f | dgrad %.3f -> %.3f | wgrad %.3f -> %.3f" %
       (tot["bf"], tot["hf"], tot["bd"], tot["hd"], tot["bw"], tot["hw"]))
+# ---- the small maps: f16x2 split-K kernel (conv_h2_sk, afd_debug_conv_path 74) against round 1's fp32 Winograd split-K kernel (75)
+tot = {k: 0.0 for k in ("sf", "wf", "sd", "wd")}
+for (ci, co, S) in shapes:
+    if ci < 32 or S > 8:
+        continue
+    cnt = bench.CONV3.count((ci, co, S))
+    x = torch.randn(B, ci, S, S, device=dev); w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+    y = torch.randn(B, co, S, S, device=dev); dx = torch.empty_like(x)
+    u = torch.empty(16 * ci * co, device=dev)
+    r = {}
+    L.afd_debug_conv_path(74)
+    k74 = L.afd_conv3x3_weight_kinds(B, ci, co, S, S)
+    L.afd_debug_conv_path(75)
+    k75 = L.afd_conv3x3_weight_kinds(B, ci, co, S, S)
+    if k74 == k75:
+        L.afd_debug_conv_path(74)
+        continue                                                  # the rule gives this layer to the same kernel either way
+    for tag, mode in (("s", 74), ("w", 75)):
+        L.afd_debug_conv_path(mode)
+        kinds = L.afd_conv3x3_weight_kinds(B, ci, co, S, S)
+        r[tag + "f"] = r[tag + "d"] = float("nan")
+        if (k74 ^ k75) & 1:
+            L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 0, kinds, s)
+            r[tag + "f"] = bench.ev_time(lambda: L.afd_conv3x3_wino_fwd(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), B, ci, co, S, S, 0, u.data_ptr(), 1, kinds, s), reps=10)
+        if (k74 ^ k75) & 2:
+            L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 0, kinds, s)
+            r[tag + "d"] = bench.ev_time(lambda: L.afd_conv3x3_wino_dgrad(y.data_ptr(), w.data_ptr(), dx.data_ptr(), None, B, ci, co, S, S, u.data_ptr(), 1, kinds, s), reps=10)
+    L.afd_debug_conv_path(74)
+    print(f"{ci:4d}->{co:4d} @{S:2d}x{S:<2d} x{cnt}: fwd wino_sk {r['wf']*1e3:6.1f} -> h2_sk {r['sf']*1e3:6.1f} | dgrad {r['wd']*1e3:6.1f} -> {r['sd']*1e3:6.1f} us", flush=True)
+    for k in tot:
+        if r[k] == r[k]:
+            tot[k] += cnt * r[k]
+print("small maps per step (ms): fwd wino_sk %.3f -> h2_sk %.3f | dgrad %.3f -> %.3f" % (tot["wf"], tot["sf"], tot["wd"], tot["sd"]))
