@@ -37,6 +37,15 @@ template <int S> struct H2Geo {
   static constexpr int NPP = (NPIX + 15) / 16 * 16;                  // channel-group stride = whole 64-bank rows: the four groups of a b128 read never collide
   static constexpr int KG = 4;                                       // 8-channel groups per 32-channel chunk
   static constexpr int TASKS = KG * NPIX, NE = (TASKS + 255) / 256;  // staging tasks (pixel record, channel group) per thread
+  // pixel of MFMA column l15 of 16-pixel sub-block `blk` of the tile -> (image i, row r, column c).  16 x 16 / 32 x 32 maps: 16
+  // consecutive pixels of a row (16 consecutive LDS records: all 64 banks once).  8 x 8 maps: two rows of 8 -- rows r and r + 4,
+  // not r and r + 1: with the haloed row stride of 10 records the second row then starts 40 records = 8 (mod 16) behind the
+  // first, so the two runs of 8 records cover the 64 banks exactly once (rows r, r + 1 collide on 2 of 16 lanes: PMC showed
+  // 2.5 conflict cycles per LDS instruction on these layers)
+  __device__ static void pixel(int blk, int l15, int& i, int& r, int& c) {
+    if (S == 8) { i = blk >> 2; r = (blk & 3) + 4 * (l15 >> 3); c = l15 & 7; }
+    else { const int q = blk * 16 + l15; i = q / (R * S); const int rem = q - i * (R * S); r = rem / S; c = rem - r * S; }
+  }
 };
 
 template <int S, int NBLK>
@@ -106,8 +115,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2(const float* __restrict__ x, c
   int bbase[PSW];
 #pragma unroll
   for (int ps = 0; ps < PSW; ++ps) {
-    const int q = (pgrp * PSW + ps) * 16 + l15;
-    const int i = q / (G::R * S), rem = q - i * (G::R * S), r = rem / S, c = rem - r * S;
+    int i, r, c;
+    G::pixel(pgrp * PSW + ps, l15, i, r, c);
     bbase[ps] = kgl * NPP + i * G::IMG + r * G::Wp + c;
   }
   f32x4 acc[2][PSW];
@@ -196,8 +205,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2(const float* __restrict__ x, c
   const float isx = h2_inv_pow2(sx);
 #pragma unroll
   for (int ps = 0; ps < PSW; ++ps) {
-    const int q = (pgrp * PSW + ps) * 16 + l15;
-    const int i = q / (G::R * S), rem = q - i * (G::R * S), r = rem / S, c = rem - r * S;
+    int i, r, c;
+    G::pixel(pgrp * PSW + ps, l15, i, r, c);
     const int b = img0 + i;
     if (b >= B) continue;
 #pragma unroll

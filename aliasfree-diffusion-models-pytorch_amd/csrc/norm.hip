@@ -209,6 +209,88 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ x,
   if (dgamma) fold_param_grads(part, gridDim.y, C, dgamma, dbeta, accumulate, red, blockIdx.y * gridDim.x + blockIdx.x, (long)gridDim.x * gridDim.y);
 }
 
+// Sample-resident backward (round 3): one workgroup per sample keeps xhat and dz of the whole sample in registers (float4 x
+// NCH per thread, as gn_fwd_reg), so x / dy are read ONCE (12 B per element instead of the 20 of the plane pass + apply pass)
+// and one launch does the job of two.  The per-channel sums (= the dgamma / dbeta partials, part (B, 2, C), and demb) are
+// segmented reductions over the HW / 4 consecutive threads that hold a channel's chunks: butterflies inside a wave, wave
+// sums through LDS when a channel spans several waves.  Needs HW % 4 == 0, HW / 4 a power of two, n / 4 <= NCH * blockDim.
+template <int NCH>
+__global__ __launch_bounds__(1024) void gn_bwd_reg(const float* __restrict__ x, const float* __restrict__ dy,
+                                                   const float* __restrict__ stats, int C, int HW,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ res, int act, float* __restrict__ dx,
+                                                   float* __restrict__ dres, float* __restrict__ part, float* __restrict__ demb) {
+  __shared__ float red[16];
+  __shared__ float seg[NCH][16][3];                   // wave sums of (dz xhat, dz, dy), chunk row k, when a channel spans waves
+  const long b = blockIdx.x;
+  const long n = (long)C * HW;
+  const int n4 = (int)(n >> 2), T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int G = HW >> 2;                              // threads per channel in a chunk row
+  const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+  const float4* x4 = reinterpret_cast<const float4*>(x + b * n);
+  const float4* d4 = reinterpret_cast<const float4*>(dy + b * n);
+  const float4* r4 = (res && act == 1) ? reinterpret_cast<const float4*>(res + b * n) : nullptr;
+  float4* z4 = dres ? reinterpret_cast<float4*>(dres + b * n) : nullptr;
+  float4 xh[NCH], dz[NCH];
+  float gk[NCH];
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int q = k * T + tid;
+    const bool ok = q < n4;
+    const int c = ok ? (q << 2) / HW : 0;
+    const float g = gamma[c], be = beta[c];
+    gk[k] = g;
+    const float4 xv = ok ? x4[q] : make_float4(mean, mean, mean, mean);
+    const float4 dv = ok ? d4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 rv = (ok && r4) ? r4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    xh[k] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+    dz[k] = make_float4(gn_dz(xh[k].x, dv.x, g, be, rv.x, act), gn_dz(xh[k].y, dv.y, g, be, rv.y, act),
+                        gn_dz(xh[k].z, dv.z, g, be, rv.z, act), gn_dz(xh[k].w, dv.w, g, be, rv.w, act));
+    if (ok && z4) z4[q] = dz[k];
+    float a = (dz[k].x * xh[k].x + dz[k].y * xh[k].y) + (dz[k].z * xh[k].z + dz[k].w * xh[k].w);
+    float s1 = (dz[k].x + dz[k].y) + (dz[k].z + dz[k].w);
+    float s3 = (dv.x + dv.y) + (dv.z + dv.w);
+    sa = fmaf(g, s1, sa); sb = fmaf(g, a, sb);
+    // the channel's sums over its G consecutive threads
+    const int gw = G < 64 ? G : 64;
+    for (int o = 1; o < gw; o <<= 1) { a += __shfl_xor(a, o, kWave); s1 += __shfl_xor(s1, o, kWave); s3 += __shfl_xor(s3, o, kWave); }
+    if (G <= 64) {
+      if (ok && (tid & (G - 1)) == 0) {
+        part[(2 * b) * C + c] = a; part[(2 * b + 1) * C + c] = s1;
+        if (demb) demb[b * C + c] = s3;
+      }
+    } else if (lane == 0) { seg[k][wv][0] = a; seg[k][wv][1] = s1; seg[k][wv][2] = s3; }
+  }
+  const float inv_n = 1.0f / (float)n;
+  const float m1 = block_sum(sa, red) * inv_n;         // (its barriers also publish seg)
+  const float m2 = block_sum(sb, red) * inv_n;
+  if (G > 64) {                                        // one thread per (chunk row, channel): add the channel's wave sums in wave order
+    const int wpc = G >> 6, cpr = T / G;               // waves per channel, channels per chunk row
+    for (int i = tid; i < NCH * cpr; i += T) {
+      const int k = i / cpr, j = i - k * cpr;
+      const int q = k * T + j * G;
+      if (q < n4) {
+        float a = 0.f, s1 = 0.f, s3 = 0.f;
+        for (int w = 0; w < wpc; ++w) { a += seg[k][j * wpc + w][0]; s1 += seg[k][j * wpc + w][1]; s3 += seg[k][j * wpc + w][2]; }
+        const int c = (q << 2) / HW;
+        part[(2 * b) * C + c] = a; part[(2 * b + 1) * C + c] = s1;
+        if (demb) demb[b * C + c] = s3;
+      }
+    }
+  }
+  float4* o4 = reinterpret_cast<float4*>(dx + b * n);
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int q = k * T + tid;
+    if (q < n4) {
+      const float g = gk[k];
+      o4[q] = make_float4(rstd * (g * dz[k].x - m1 - xh[k].x * m2), rstd * (g * dz[k].y - m1 - xh[k].y * m2),
+                          rstd * (g * dz[k].z - m1 - xh[k].z * m2), rstd * (g * dz[k].w - m1 - xh[k].w * m2));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // LayerNorm over C for every pixel of an NCHW tensor (tokens = pixels)
 // ------------------------------------------------------------------------------------------
@@ -432,7 +514,12 @@ static inline int gs_grid(long total, int block = 256) {
 }  // namespace afd
 using namespace afd;
 
+static int g_gn_bwd_mode = 0;      // afd_debug_norm_path 0 / 1: the sample-resident GroupNorm backward by rule / never (plane pass + apply pass)
+
 extern "C" {
+
+int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, int accumulate, afd_stream_t st);
+int afd_debug_norm_path(int mode) { g_gn_bwd_mode = mode == 1 ? 1 : 0; return AFD_OK; }
 
 int afd_groupnorm1_fwd(const float* x, float* y, float* stats_out, int B, int C, int HW, float eps,
                        const float* gamma, const float* beta, const float* res, int act, const float* emb,
@@ -470,13 +557,30 @@ int afd_groupnorm1_bwd(const float* x, const float* dy, const float* stats, int 
   AFD_REQUIRE(!have_partials || (!dres && !demb && act == 0 && !res), "afd_groupnorm1_bwd: have_partials only for the plain form");
   hipStream_t s = as_stream(st);
   const long planes = (long)B * C;
+  const long n = (long)C * HW;
+  AFD_REQUIRE(B <= 65535, "afd_groupnorm1_bwd: batch too large for the grid");
+  // sample-resident form: x and dy read once, one launch (+ the column sums when the caller wants dgamma / dbeta here)
+  const int G = HW / 4;
+  const bool vec = HW % 4 == 0 && (G & (G - 1)) == 0 && G <= 1024 && n <= 32768 && g_gn_bwd_mode == 0 &&
+                   ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)res | (uintptr_t)dres) & 15) == 0);
+  if (!have_partials && vec) {
+    const long n4 = n / 4;
+#define AFD_GNB_LAUNCH(NCH, T) hipLaunchKernelGGL(gn_bwd_reg<NCH>, dim3(B), dim3(T), 0, s, x, dy, stats, C, HW, gamma, beta, res, act, dx, dres, part, demb)
+    if (n4 <= 256 && G <= 256) AFD_GNB_LAUNCH(1, 256);
+    else if (n4 <= 512 && G <= 256) AFD_GNB_LAUNCH(2, 256);
+    else if (n4 <= 1024 && G <= 256) AFD_GNB_LAUNCH(4, 256);
+    else if (n4 <= 2048) AFD_GNB_LAUNCH(2, 1024);
+    else if (n4 <= 4096) AFD_GNB_LAUNCH(4, 1024);
+    else AFD_GNB_LAUNCH(8, 1024);
+#undef AFD_GNB_LAUNCH
+    if (dgamma) return afd_colsum2(part, dgamma, dbeta, B, C, accumulate, st);
+    return check_launch("afd_groupnorm1_bwd");
+  }
   if (!have_partials)
     hipLaunchKernelGGL(gn_bwd_plane, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, x, dy, stats, C, HW, planes, gamma, beta, res, act, dres, part, demb);
-  const long n = (long)C * HW;
   int slices = (int)((n + 8191) / 8192);               // ~32 elements (8 float4) per thread
   if (slices < 1) slices = 1;
   if (slices > 64) slices = 64;
-  AFD_REQUIRE(B <= 65535, "afd_groupnorm1_bwd: batch too large for the grid");
   hipLaunchKernelGGL(gn_bwd_apply, dim3(slices, B), dim3(256), 0, s, x, dy, stats, part, C, HW, gamma, beta, res, act, dx, dgamma, dbeta, accumulate);
   return check_launch("afd_groupnorm1_bwd");
 }

@@ -356,10 +356,15 @@ class GroupNorm1(_Fn):
         part = torch.empty(B * C * 2, device=x.device, dtype=torch.float32)
         demb = torch.empty(B, C, device=x.device, dtype=torch.float32) if ctx.has_emb else None
         dg, db, acc, (dgamma, dbeta) = _gn_param_targets(C, gamma, beta, x.device)
+        defer = acc and _GradMode.side is not None          # the two column sums of part (B, 2, C): folded with the other layers'
         lib().afd_groupnorm1_bwd(_p(x), _p(dy), _p(stats), B, C, H * W, _p(gamma), _p(beta), _p(res), ctx.act,
                                  _p(dx), _p(dres) if (res is not None and ctx.act == 1) else None, _p(part), _p(demb), 0,
-                                 _p(dg), _p(db), acc, _stream())
-        if acc:
+                                 None if defer else _p(dg), None if defer else _p(db), acc, _stream())
+        if defer:
+            pp = _p(part)
+            defer_to_side_stream(None, fold_desc(pp, _p(dg), C, B, stride=2 * C) + fold_desc(pp + 4 * C, _p(db), C, B, stride=2 * C),
+                                 part, writes=(gamma, beta))
+        elif acc:
             _wrote(gamma, beta)
         return dx, dgamma, dbeta, dres, demb, None
 

@@ -102,6 +102,9 @@ int afd_filt_act_bwd(const float* x, const float* dy, float* dv, int B, int C, i
 int afd_groupnorm1_fwd(const float* x, float* y, float* stats_out, int B, int C, int HW, float eps,
                        const float* gamma, const float* beta, const float* res, int act, const float* emb,
                        afd_stream_t stream);
+/* test hook: 0 = the sample-resident backward (one launch, x / dy read once) wherever the sample fits the registers
+ * (C*HW <= 32768, HW/4 a power of two: default), 1 = always the plane pass + apply pass of round 1 */
+int afd_debug_norm_path(int mode);
 int afd_groupnorm1_bwd(const float* x, const float* dy, const float* stats, int B, int C, int HW,
                        const float* gamma, const float* beta, const float* res, int act,
                        float* dx, float* dres, float* dgamma_dbeta_partial /* B*C*2 floats, (B,2,C) */, float* demb /* (B,C) or NULL */,

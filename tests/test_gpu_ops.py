@@ -171,10 +171,23 @@ def _gn_oracle(x, gamma, beta, res, emb, act):
     return z
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (3, 32, 32, 32), (2, 64, 32, 32), (2, 256, 4, 4), (2, 5, 3, 3), (1, 16, 16, 16)])
+# (3,32,32,32): sample-resident backward, a channel = 4 waves of the 1024-thread workgroup; (2,64,32,32): the plane + apply passes
+# (sample beyond the registers); (2,256,4,4), (3,128,8,8), (2,64,16,16), (3,128,4,4): the UNet's other plain sites (channels of
+# 4 / 16 / 64 threads); (2,5,3,3): no vector path; (2,4,64,64): a channel = a whole 1024-thread workgroup
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (3, 32, 32, 32), (2, 64, 32, 32), (2, 256, 4, 4), (2, 5, 3, 3), (1, 16, 16, 16),
+                                   (3, 128, 8, 8), (2, 64, 16, 16), (3, 128, 4, 4), (2, 4, 64, 64), (2, 24, 8, 8)])
 @pytest.mark.parametrize("mode", ["plain", "res_gelu", "emb", "gelu"])
-def test_groupnorm(A, shape, mode):
-    _, ops, dev = A
+@pytest.mark.parametrize("bwd_form", ["rule", "two_pass"])
+def test_groupnorm(A, shape, mode, bwd_form):
+    afdm, ops, dev = A
+    afdm.lib().afd_debug_norm_path(1 if bwd_form == "two_pass" else 0)
+    try:
+        _groupnorm_case(ops, dev, shape, mode)
+    finally:
+        afdm.lib().afd_debug_norm_path(0)
+
+
+def _groupnorm_case(ops, dev, shape, mode):
     B, C, H, W = shape
     g = _g(sum(shape))
     x = torch.randn(shape, generator=g) * 1.7 + 0.3

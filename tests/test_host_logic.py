@@ -57,7 +57,13 @@ def test_conv_dispatch_rules_are_consistent_on_the_host():
             assert form in (0, 1, 3, 4)
             assert L.afd_conv_wgrad_workspace_bytes(B, ci, co, S, S, 3) >= 4 * co * ci * 9
     assert L.afd_conv3x3_weight_kinds(256, 128, 128, 16, 16) == 3 and L.afd_conv3x3_weight_kinds(4, 128, 128, 16, 16) == 0
-    assert L.afd_conv3x3_weight_kinds(256, 128, 128, 4, 4) == 0 and L.afd_conv3x3_weight_kinds(256, 24, 40, 8, 8) == 0
+    assert L.afd_conv3x3_weight_kinds(256, 128, 128, 4, 4) == 3 and L.afd_conv3x3_weight_kinds(256, 24, 40, 8, 8) == 0   # (4x4: the f16x2 split-K kernel)
+    assert L.afd_conv3x3_weight_kinds(16, 128, 128, 4, 4) == 0                                                                # too few slices: Winograd split-K
+    try:
+        L.afd_debug_conv_path(75)
+        assert L.afd_conv3x3_weight_kinds(256, 128, 128, 4, 4) == 0 and L.afd_conv3x3_wino_workspace_bytes(256, 128, 128, 4, 4, 0) > 0
+    finally:
+        L.afd_debug_conv_path(74)
     assert L.afd_conv_wgrad_form(256, 128, 128, 16, 16, 3) == 4 and L.afd_conv_wgrad_form(256, 128, 128, 4, 4, 3) == 4
     assert L.afd_conv_wgrad_form(256, 3, 32, 32, 32, 3) == 3 and L.afd_conv_wgrad_form(256, 24, 40, 8, 8, 3) == 0
     assert L.afd_conv_wgrad_form(256, 32, 96, 32, 32, 1) == 4 and L.afd_conv_wgrad_form(256, 32, 3, 32, 32, 1) == 0

@@ -5,6 +5,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 reps = int(sys.argv[1])
@@ -14,9 +15,15 @@ for d in sys.argv[2:]:
         seen = set()
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "afd::" not in k:
+            if "afd::" in k:
+                kn = k.split("afd::")[1].split("(")[0]
+            elif k.startswith("_ZN3afd"):                      # (kernels with _Float16 vector arguments stay mangled in the trace)
+                m = re.match(r"_ZN3afd(\d+)", k)
+                n = int(m.group(1)); name = k[m.end():m.end() + n]; rest = k[m.end() + n:]
+                targs = re.findall(r"L[ib](\d+)E", rest.split("EEv")[0]) if rest.startswith("I") else []
+                kn = name + ("<" + ", ".join(targs) + ">" if targs else "")
+            else:
                 continue
-            kn = k.split("afd::")[1].split("(")[0]
             out[kn][r["Counter_Name"]] += float(r["Counter_Value"]) / reps
             if (kn, r["Dispatch_Id"]) not in seen and d == sys.argv[2]:
                 seen.add((kn, r["Dispatch_Id"]))
