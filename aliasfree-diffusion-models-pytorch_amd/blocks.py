@@ -154,9 +154,11 @@ class _Stage(nn.Module):
 
     def _emb(self, t):
         pre, self._emb_pre = self._emb_pre, None
-        if pre is not None and pre[0] is t:
-            return pre[1]
         lin = self.emb_layer[1]
+        if pre is not None and pre[0] is t:
+            # the value is there already; the autograd node is created HERE, in this stage's forward, so that backward
+            # reaches it (and this stage's emb_layer gradients) when it reaches the stage -- not at the very end
+            return ops.SiluLinearPre.apply(pre[1], t, lin.weight, lin.bias) if torch.is_grad_enabled() else pre[1]
         return ops.SiluLinear.apply(t, lin.weight, lin.bias)
 
 

@@ -1027,11 +1027,13 @@ class SiluLinear(_Fn):
 def silu_linear_batched(temb, layers):
     """The emb_layer of several stages (each nn.Sequential(nn.SiLU(), nn.Linear(emb_dim, C_i)), ddpm_utils.py:208-214) on the SAME
     time embedding: ONE forward launch for all of them (the input exists as soon as the UNet forward starts, so one launch
-    replaces six small dependent ones) -> [out_0, out_1, ...].  `layers` = [(weight, bias), ...]; temb must not need a gradient
-    (the conditional model keeps the per-stage op).  Backward stays PER STAGE: every output leaves through its own autograd
-    node (SiluLinearPre), which produces and reports that stage's parameter gradients as soon as its dout arrives -- one
-    node for all six would hold every stage's gradient (and with it three of the four data-parallel buckets) back until the
-    first encoder stage's backward."""
+    replaces six small dependent ones) -> [out_0, out_1, ...] (plain tensors, no autograd history).  `layers` = [(weight,
+    bias), ...]; temb must not need a gradient (the conditional model keeps the per-stage op).  Backward stays PER STAGE:
+    the stage wraps its output in its own autograd node WHEN ITS FORWARD RUNS (SiluLinearPre, see blocks._Stage._emb).
+    One node for all six would hold every stage's gradient (and with it three of the four data-parallel buckets) back
+    until the first encoder stage's backward; and six nodes created here, at the start of the forward, would carry the
+    lowest sequence numbers of the graph -- autograd runs ready nodes highest-sequence first, so they would all run at
+    the very END of backward (measured: the decoder bucket became ready at flush 24 of 25)."""
     import ctypes, struct
     ws, bs = [w for w, _ in layers], [b for _, b in layers]
     _chk(temb, *ws, *bs)
@@ -1042,9 +1044,7 @@ def silu_linear_batched(temb, layers):
     desc = b"".join(struct.pack("<QQQi4x", _p(w) or 0, _p(b) or 0, _p(o), w.shape[0]) for w, b, o in zip(ws, bs, outs))
     buf = ctypes.create_string_buffer(desc, len(desc))
     lib().afd_silu_linear_fwd_batched(_p(temb), ctypes.addressof(buf), len(ws), B, K, _stream())
-    if not torch.is_grad_enabled():
-        return outs
-    return [SiluLinearPre.apply(o, temb, w, b) for o, w, b in zip(outs, ws, bs)]
+    return outs
 
 
 class SiluLinearPre(_Fn):
