@@ -10,7 +10,7 @@ import re
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "afd.h")
-LIBPATH = os.path.join(_PKG, "libafd_hip.so")
+LIBPATH = os.environ.get("AFD_LIBPATH") or os.path.join(_PKG, "libafd_hip.so")     # (AFD_LIBPATH: another build of the SAME library, for same-box A/B runs)
 
 _CTYPES = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,

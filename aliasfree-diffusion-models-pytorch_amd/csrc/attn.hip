@@ -333,6 +333,7 @@ template <int D, int R> static void launch_dkv(const float* qkv, const float* d_
 
 namespace afd {   // attn_mfma.hip: d = 8 / 16 passes with the d-contractions on the matrix cores
 bool attn_mfma8_ok(int d, int L);
+void attn_pv_set(int m);
 void attn_mfma8_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d, int L, float sc, hipStream_t s);
 void attn_mfma8_bwd_dq(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta,
                        int B, int heads, int d, int L, float sc, hipStream_t s);
@@ -347,8 +348,9 @@ static int g_attn_rows = 0;      // tuning hook: 0 = default (MFMA path for d = 
 extern "C" {
 
 int afd_debug_attn_rows(int r) {
+  if (r == 20 || r == 21) { attn_pv_set(r - 20); return AFD_OK; }                   // rank-8 products of the d = 8 MFMA kernels: vector pipe / fp16 matrix pipe (default)
   if (r == 10 || r == 11) { g_attn_mfma_bwd_all = r - 10; return AFD_OK; }         // MFMA d = 8 backward at L = 1024 off / on (default on)
-  AFD_REQUIRE(r == 0 || r == 1 || r == 2 || r == 4, "afd_debug_attn_rows: r must be 0, 1, 2, 4 (rows per lane of the VALU kernels), 10 or 11");
+  AFD_REQUIRE(r == 0 || r == 1 || r == 2 || r == 4, "afd_debug_attn_rows: r must be 0, 1, 2, 4 (rows per lane of the VALU kernels), 10, 11, 20 or 21");
   g_attn_rows = r;
   return AFD_OK;
 }

@@ -11,6 +11,7 @@
 // Scores live in the log2 domain: log2(e)/sqrt(d) is folded into the Q (K) fragments, exp is v_exp_f32.
 // Requirements: d in {8, 16}, L % 256 == 0 (others use attn.hip).  Deterministic, no atomics.
 #include "common.h"
+#include "h2_common.h"
 
 namespace afd {
 
@@ -202,6 +203,156 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const float* __restrict_
       if (half == 0) o[((long)b * C + h * D + d) * L + qi] = t * inv;
     }
     if (half == 0) lse[((long)b * heads + h) * L + qi] = (m[j] + __builtin_amdgcn_logf(lt)) * kLn2;   // v_log_f32 = log2
+  }
+}
+
+// P' = exp2(s - off) for the 16 scores of a lane, split into two fp16 pieces as the B operands of two (k = registers 0..7,
+// 8..15) x two (piece) MFMAs: one packed conversion per pair and piece
+using h2v = __attribute__((ext_vector_type(2))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+__device__ __forceinline__ void pv_split16(const f32x16& sc, float off, h8 (&p1)[2], h8 (&p2)[2]) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    u32x4 w1, w2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float x0 = __builtin_amdgcn_exp2f(sc[8 * g + 2 * q] - off), x1 = __builtin_amdgcn_exp2f(sc[8 * g + 2 * q + 1] - off);
+      const h2v a = __builtin_convertvector((f2){x0, x1}, h2v);
+      const h2v c = __builtin_convertvector((f2){x0 - (float)a[0], x1 - (float)a[1]}, h2v);
+      w1[q] = __builtin_bit_cast(uint32_t, a);
+      w2[q] = __builtin_bit_cast(uint32_t, c);
+    }
+    p1[g] = __builtin_bit_cast(h8, w1);
+    p2[g] = __builtin_bit_cast(h8, w2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, round 3: P V on the fp16 matrix pipe too.
+// The kernel above is bound by vector instructions: per (query, key) pair a max, a sub, a quarter-rate exp, an add (the
+// row sum) and four packed FMAs (the rank-8 update O += p V[key]) = 12 issue slots.  Here the S^T tile that the first MFMA
+// leaves in the accumulator layout (lane = query, 16 registers = 16 keys) is ITSELF the B operand of a second product:
+//   O'^T[m][query] += sum_key A[m][key] * P'[key][query],   v_mfma_f32_32x32x16_f16, k-slot (half, j) <-> key acc_row(8 g + j, half)
+// with P' = 2^14 P split into two fp16 pieces (P <= 1: 22 bits; the factor cancels against the row sum) and the rows of A
+//   m = 0..7: V piece 1 (d = m),  m = 8..15: V piece 2,  m = 16, 20: ones (their output row IS the row sum),  others 0.
+// V is scaled by a power of two that follows the data (h2_common.h: the per-stage maximum; when it would overflow fp16 the
+// scale is lowered and the running sums carried over).  Four MFMAs per 32 x 32 tile replace 64 packed FMAs + 16 adds; what is
+// left on the vector pipe per pair is max/2 + sub + exp + ~2 conversion slots: 7.5 instead of 12.  The piece products
+// v1 p1 + v2 p1 + v1 p2 (+ v2 p2) are exact in the fp32 accumulator; the result is fp32-class (2^-22 per product).
+// Output: lane (query, half) ends with d = 4 half .. 4 half + 3 of its query -- no cross-lane step.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_fwd_pv(const float* __restrict__ qkv, float* __restrict__ o,
+                                                    float* __restrict__ lse, int heads, int L, float scale) {
+  static_assert(D == 8, "attn_fwd_pv: head dim 8");
+  __shared__ __attribute__((aligned(16))) uint32_t Kp[3 * kTK * 4];            // K pieces (A fragments of S^T)
+  __shared__ __attribute__((aligned(16))) _Float16 Va[2 * 2 * 2 * 32 * 8];     // [key tile][g][half][m][8]: A fragments of P V
+  __shared__ float wmax[4];
+  const int b = blockIdx.z, h = blockIdx.y, C = heads * D;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+  const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
+  const float* kp = qp + (long)C * L;
+  const float* vp = kp + (long)C * L;
+  const int q0 = blockIdx.x * 256 + wv * 64;
+  bf8 bq[2][3];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = qp[(long)d * L + q0 + j * 32 + l31] * (scale * kLog2e);
+    row_frags<D>(x, half, bq[j]);
+  }
+  // the constant rows of A: ones at m = 16 and 20 (the row sum lands in accumulator register 8 of both lane halves), else 0
+  for (int i = threadIdx.x; i < 2 * 2 * 2 * 16 * 8; i += 256) {
+    const int rec = i >> 3, m = 16 + (rec & 15), blk = rec >> 4;
+    Va[(blk * 32 + m) * 8 + (i & 7)] = (m == 16 || m == 20) ? (_Float16)1.0f : (_Float16)0.0f;
+  }
+  float m[2] = {-INFINITY, -INFINITY};
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float sv = __uint_as_float(kH2ScaleCapBits);                        // running power-of-two scale of V
+
+  const int jp0 = threadIdx.x >> 6, rr = threadIdx.x & 63;           // staging: d-pair (2 jp0, 2 jp0 + 1) of key row rr
+  // where this thread's V elements go: key rr = 32 kt + rho, rho = (r & 3) + 8 (r >> 2) + 4 half' -> k-slot (half', j = r & 7) of MFMA g = r >> 3
+  const int rho = rr & 31, vh = (rho >> 2) & 1, vr = (rho & 3) + 4 * (rho >> 3);
+  const int vbase = ((((rr >> 5) * 2 + (vr >> 3)) * 2 + vh) * 32) * 8 + (vr & 7);       // + m * 8
+  float kreg[2], vreg[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      kreg[hh] = kp[(long)(2 * jp0 + hh) * L + k0 + rr];
+      vreg[hh] = vp[(long)(2 * jp0 + hh) * L + k0 + rr];
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < L; k0 += kTK) {
+    {
+      const float mv = wave_amax(fmaxf(fabsf(vreg[0]), fabsf(vreg[1])));
+      if (lane == 0) wmax[wv] = mv;
+    }
+    __syncthreads();                                                   // the previous stage's fragment reads are done; the maxima are visible
+    {
+      const float sn = fminf(sv, h2_scale_for(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+      if (sn != sv) {                                                  // (uniform) carry the V-weighted sums over to the lower scale
+        const float f = sn * h2_inv_pow2(sv);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) acc[j][r] *= f;
+        sv = sn;
+      }
+    }
+    stage_pieces<D>(Kp, rr, jp0, kreg[0], kreg[1]);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      _Float16 a, c;
+      h2_split(vreg[hh], sv, a, c);
+      Va[vbase + (2 * jp0 + hh) * 8] = a;
+      Va[vbase + (2 * jp0 + hh + 8) * 8] = c;
+    }
+    __syncthreads();
+    if (k0 + kTK < L) fetch(k0 + kTK);
+#pragma unroll
+    for (int kt = 0; kt < kTK / 32; ++kt) {
+      bf8 ak[3];
+      load_frags<D>(Kp, kt * 32 + l31, half, ak);
+      const h8* va = reinterpret_cast<const h8*>(Va) + ((kt * 2) * 2 + half) * 32 + l31;
+      const h8 av0 = va[0], av1 = va[2 * 32];                          // g = 0, 1
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 sc = dotx3<D>(ak, bq[j]);
+        float mx = fmaxf(sc[0], sc[1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sc[r]), sc[r + 1]);
+        mx = fmaxf(mx, xhalf(mx));
+        const float mn = fmaxf(m[j], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m[j] - mn);         // m = -inf first: exp2(-inf) = 0
+        m[j] = mn;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) acc[j][r] *= alpha;                // eight sums + the row sum
+        const float off = mn - 14.0f;                                  // P' = 2^14 P
+        h8 p1[2], p2[2];
+        pv_split16(sc, off, p1, p2);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av0, p1[0], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av1, p1[1], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av0, p2[0], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av1, p2[1], acc[j], 0, 0, 0);
+      }
+    }
+  }
+  const float isv = h2_inv_pow2(sv);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float lt = acc[j][8];                                        // 2^14 x the softmax denominator
+    const float inv = isv / lt;
+    const int qi = q0 + j * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      o[((long)b * C + h * D + 4 * half + i) * L + qi] = (acc[j][i] + acc[j][4 + i]) * inv;
+    if (half == 0) lse[((long)b * heads + h) * L + qi] = (m[j] - 14.0f + __builtin_amdgcn_logf(lt)) * kLn2;   // v_log_f32 = log2
   }
 }
 
@@ -431,8 +582,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const float* __restr
 
 // host-side launchers used by attn.hip
 bool attn_mfma8_ok(int d, int L) { return (d == 8 || d == 16) && L % 256 == 0; }
+static int g_attn_pv = 1;           // afd_debug_attn_rows 20 / 21: rank-8 products of the d = 8 kernels on the vector pipe (round 2) / on the fp16 matrix pipe
+void attn_pv_set(int m) { g_attn_pv = m; }
 void attn_mfma8_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d, int L, float sc, hipStream_t s) {
-  if (d == 8) hipLaunchKernelGGL(attn_fwd_mfma<8>, dim3(L / 256, heads, B), dim3(256), 0, s, qkv, o, lse, heads, L, sc);
+  if (d == 8 && g_attn_pv) hipLaunchKernelGGL(attn_fwd_pv<8>, dim3(L / 256, heads, B), dim3(256), 0, s, qkv, o, lse, heads, L, sc);
+  else if (d == 8) hipLaunchKernelGGL(attn_fwd_mfma<8>, dim3(L / 256, heads, B), dim3(256), 0, s, qkv, o, lse, heads, L, sc);
   else hipLaunchKernelGGL(attn_fwd_mfma<16>, dim3(L / 256, heads, B), dim3(256), 0, s, qkv, o, lse, heads, L, sc);
 }
 // dQ pass (+ delta) for d in {8, 16}; the dK / dV pass on these kernels only at d = 8: at d = 16 one key tile per wave is all

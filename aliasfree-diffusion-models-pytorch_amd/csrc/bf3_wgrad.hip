@@ -366,8 +366,8 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_bf3(const float* __restrict__
 
   float4 ra[NT][2], rb[2][2];
   auto fetch = [&](int t) {
-    const long P0 = 32L * t;
-    const long b = P0 / L, p = P0 - b * L + 8 * kgl;
+    const long P0 = 32L * t + 8 * kgl;                                 // this lane's 8 pixels (L % 8 == 0: they never straddle two images)
+    const long b = P0 / L, p = P0 - b * L;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const float4* q = reinterpret_cast<const float4*>(dy + (b * N + n0 + 16 * i + l15) * L + p);
@@ -614,7 +614,7 @@ static int g_pwbf3_mode = 0;       // afd_debug_conv_path 88 / 89: the 1x1 form 
 void pw_wgrad_bf3_set_mode(int m) { g_pwbf3_mode = m; }
 int pw_wgrad_bf3_plan(int B, int Cin, int Cout, int L, int* sps, int* nsteps, int* nr, int* nt) {
   if (g_wgbf3_mode == 1 || g_pwbf3_mode == 1) return 0;
-  if (Cin % 32 || Cout % 32 || L % 32) return 0;
+  if (Cin % 32 || Cout % 32 || L % 8 || ((long)B * L) % 32) return 0;    // (L = 16: a 32-pixel step takes two 4x4 images)
   if ((long)B * L * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return 0;
   const int NT = Cout % 48 == 0 ? 3 : 2;
   const int roles = (Cout / (16 * NT)) * (Cin / 32);

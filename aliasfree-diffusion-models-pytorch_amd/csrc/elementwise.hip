@@ -188,14 +188,17 @@ __global__ void silu_linear_fwd_batched_k(const float* __restrict__ temb, SiluBa
   s = wave_sum(s);
   if (lane == 0) d.out[i][(long)b * d.N[i] + n] = s + (d.bias[i] ? d.bias[i][n] : 0.f);
 }
-// dw[n,k] = sum_b dout[b,n] silu(temb[b,k]).  Block = one output row n x 32 columns k x 8 batch groups;
-// the 8 partial sums meet in LDS (fixed order).  Row blockIdx.y == N (present when db != NULL) holds the bias gradient
-// db[n] = sum_b dout[b,n] instead: 32 outputs n per block, the same 8 batch groups -- one launch for both.
+// dw[n,k] = sum_b dout[b,n] silu(temb[b,k]).  Block = EIGHT output rows n x 32 columns k x 8 batch groups: a thread evaluates
+// silu(temb[b,k]) once per batch row and feeds eight running sums (the eight dout values of a row are one broadcast 32-byte
+// read); the 8 batch groups' partial sums meet in LDS (fixed order).  (One row per block, the first form, spent 20 us per
+// stage on 2-8 MFLOP: 32 dependent iterations of two loads and one FMA.)  Row block blockIdx.y == ceil(N / 8) (present when
+// db != NULL) holds the bias gradient db[n] = sum_b dout[b,n] instead: 32 outputs n per block -- one launch for both.
 __global__ __launch_bounds__(256) void silu_linear_dw_k(const float* __restrict__ temb, const float* __restrict__ dout, float* __restrict__ dw,
                                                         float* __restrict__ db, int B, int K, int N, int accumulate) {
-  __shared__ float red[8][33];
+  __shared__ float red[8][8][33];
   const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
-  if ((int)blockIdx.y == N) {
+  const int nrb = (N + 7) >> 3;
+  if ((int)blockIdx.y == nrb) {
     const int n = blockIdx.x * 32 + l;
     if (blockIdx.x * 32 >= N) return;
     float s0 = 0.f, s1 = 0.f;
@@ -204,34 +207,38 @@ __global__ __launch_bounds__(256) void silu_linear_dw_k(const float* __restrict_
       for (; b + 8 < B; b += 16) { s0 += dout[(long)b * N + n]; s1 += dout[(long)(b + 8) * N + n]; }
       if (b < B) s0 += dout[(long)b * N + n];
     }
-    red[g][l] = s0 + s1;
+    red[0][g][l] = s0 + s1;
     __syncthreads();
     if (g == 0 && n < N) {
       float t = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t += red[j][l];
+      for (int j = 0; j < 8; ++j) t += red[0][j][l];
       db[n] = accumulate ? db[n] + t : t;
     }
     return;
   }
-  const int n = blockIdx.y;
+  const int n0 = blockIdx.y * 8;
   const int k = blockIdx.x * 32 + l;
-  float s0 = 0.f, s1 = 0.f;
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
   if (k < K) {
-    int b = g;
-    for (; b + 8 < B; b += 16) {
-      s0 += dout[(long)b * N + n] * silu(temb[(long)b * K + k]);
-      s1 += dout[(long)(b + 8) * N + n] * silu(temb[(long)(b + 8) * K + k]);
+    for (int b = g; b < B; b += 8) {
+      const float a = silu(temb[(long)b * K + k]);
+      const float* d = dout + (long)b * N + n0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] = fmaf(n0 + j < N ? d[j] : 0.f, a, s[j]);
     }
-    if (b < B) s0 += dout[(long)b * N + n] * silu(temb[(long)b * K + k]);
   }
-  red[g][l] = s0 + s1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[j][g][l] = s[j];
   __syncthreads();
-  if (g == 0 && k < K) {
+  // thread (j = g, l): output row n0 + g, column k
+  if (k < K && n0 + g < N) {
     float t = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t += red[j][l];
-    float* o = dw + (long)n * K + k;
+    for (int q = 0; q < 8; ++q) t += red[g][q][l];
+    float* o = dw + (long)(n0 + g) * K + k;
     *o = accumulate ? *o + t : t;
   }
 }
@@ -406,7 +413,7 @@ int afd_silu_linear_bwd(const float* temb, const float* w, const float* dout, fl
   AFD_REQUIRE(temb && w && dout && dw && B > 0 && K > 0 && N > 0, "afd_silu_linear_bwd: bad argument");
   hipStream_t s = as_stream(st);
   AFD_REQUIRE(!dbias || (N + 31) / 32 <= (K + 31) / 32, "afd_silu_linear_bwd: N > K is not covered");   // (the bias row rides in the dW grid)
-  hipLaunchKernelGGL(silu_linear_dw_k, dim3((K + 31) / 32, dbias ? N + 1 : N), dim3(256), 0, s, temb, dout, dw, dbias, B, K, N, accumulate);
+  hipLaunchKernelGGL(silu_linear_dw_k, dim3((K + 31) / 32, (N + 7) / 8 + (dbias ? 1 : 0)), dim3(256), 0, s, temb, dout, dw, dbias, B, K, N, accumulate);
   if (dtemb) hipLaunchKernelGGL(silu_linear_dx_k, dim3((unsigned)(((long)B * K + 255) / 256)), dim3(256), 0, s, temb, w, dout, dtemb, B, K, N);
   return check_launch("afd_silu_linear_bwd");
 }

@@ -420,8 +420,8 @@ __global__ __launch_bounds__(512, 1) void pw_wgrad_h2(const float* __restrict__ 
 
   float4 ra[NT][2], rb[2][2];
   auto fetch = [&](int t) {
-    const long P0 = 32L * t;
-    const long b = P0 / L, p = P0 - b * L + 8 * kgl;
+    const long P0 = 32L * t + 8 * kgl;                                 // this lane's 8 pixels (L % 8 == 0: they never straddle two images)
+    const long b = P0 / L, p = P0 - b * L;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const float4* q = reinterpret_cast<const float4*>(dy + (b * N + n0 + 16 * i + l15) * L + p);
