@@ -334,6 +334,8 @@ template <int D, int R> static void launch_dkv(const float* qkv, const float* d_
 namespace afd {   // attn_mfma.hip: d = 8 / 16 passes with the d-contractions on the matrix cores
 bool attn_mfma8_ok(int d, int L);
 void attn_pv_set(int m);
+bool attn_fused_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta, int B, int heads,
+                    int d, int L, float sc, hipStream_t s);
 void attn_mfma8_fwd(const float* qkv, float* o, float* lse, int B, int heads, int d, int L, float sc, hipStream_t s);
 void attn_mfma8_bwd_dq(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta,
                        int B, int heads, int d, int L, float sc, hipStream_t s);
@@ -388,6 +390,7 @@ int afd_attn_bwd(const float* qkv, const float* o, const float* d_o, const float
   hipStream_t s = as_stream(st);
   const float sc = 1.0f / sqrtf((float)d);
   if (g_attn_rows == 0 && attn_mfma8_ok(d, L) && (L < 1024 || g_attn_mfma_bwd_all)) {
+    if (attn_fused_bwd(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, d, L, sc, s)) return check_launch("afd_attn_bwd");
     attn_mfma8_bwd_dq(qkv, o, d_o, lse, dqkv, delta_ws, B, heads, d, L, sc, s);
     if (d == 8) attn_mfma8_bwd_dkv(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s);
     else launch_dkv<16, 2>(qkv, d_o, lse, delta_ws, dqkv, B, heads, L, sc, s);       // (the d = 16 dK / dV pass stays on the vector kernel)

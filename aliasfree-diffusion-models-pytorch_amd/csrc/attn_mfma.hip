@@ -336,10 +336,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pv(const float* __restrict__ 
         const float off = mn - 14.0f;                                  // P' = 2^14 P
         h8 p1[2], p2[2];
         pv_split16(sc, off, p1, p2);
+        __builtin_amdgcn_s_setprio(2);                                 // matrix-pipe phases issue ahead of the other wave's vector work
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av0, p1[0], acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av1, p1[1], acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av0, p2[0], acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av1, p2[1], acc[j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
       }
     }
   }
@@ -575,6 +577,321 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward in ONE pass, round 3 (d = 8): every product on the matrix pipes.
+//
+// Round 2's two passes each recomputed S, dP and the exponentials and ran their rank-8 updates as packed vector FMAs: 12 + 17
+// vector issue slots per (query, key) pair.  Here a workgroup owns 256 keys of one (batch, head) at a time (a wave: two tiles
+// of 32), streams the queries in stages of 64 and computes S / dP (bf16x3 MFMAs, as before), P' = 2^14 P and dS' = s_ds dS
+// ONCE, in the layout lane = key, 16 registers = 16 queries.  Both tiles, split into two fp16 pieces, are then operands:
+//   dV'^T[m][key] += sum_q GA[m][q] P'[q][key]      A rows: dO pieces (m = d, d + 8)         } the tile is the B operand:
+//   dK'^T[m][key] += sum_q QA[m][q] dS'[q][key]     A rows: Q pieces                          } contraction over registers
+//   dS'^T = sum_g dS'_g as A x (a 0/1 selection matrix as B): the SAME registers read as an A operand give the tile with the
+//           roles of lanes and registers swapped -- the matrix pipe transposes it, exactly (one non-zero product per output);
+//   dQ'^T[m][query] += sum_key KA[m][key] dS'^T[key][query]                                    (its pieces re-packed: 16 cvt)
+// 22 MFMAs (32x32x16) per 32 x 32 tile against ~15 vector slots per pair (exp, the softmax algebra, three fp16 splits): half the
+// vector work of the two passes.  Scales (powers of two, h2_common.h): Q, dO per workgroup (running, from each stage's
+// maximum), K per key block and wave, dS per wave from the bound |dS| <= max_key |V|_1 max|dO| + max|delta|; every change
+// rescales the affected accumulators (exact).  dQ: each wave's partial for a 32-query tile (its 64 keys) is unscaled, the four
+// waves' partials meet in LDS in wave order and are added to global memory by this workgroup alone, key block after key block
+// (no other workgroup touches this (batch, head)): deterministic, no atomics, no slabs.  delta = rowsum(dO o O) comes from a
+// small kernel ahead.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_k(const float* __restrict__ o, const float* __restrict__ d_o, float* __restrict__ delta,
+                                                    int heads, int D, int L, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;                 // (b, h, q)
+  if (i >= total) return;
+  const int q = i % L; const long bh = i / L;
+  const float* po = o + bh * D * L + q;
+  const float* pg = d_o + bh * D * L + q;
+  float s = 0.f;
+  for (int d = 0; d < D; ++d) s = fmaf(pg[(long)d * L], po[(long)d * L], s);
+  delta[i] = s;
+}
+
+// two fp16 pieces of 16 fp32 values (the registers of one accumulator tile) as the operands of the two k-groups
+__device__ __forceinline__ void split16(const f32x16& v, h8 (&p1)[2], h8 (&p2)[2]) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    u32x4 w1, w2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float x0 = v[8 * g + 2 * q], x1 = v[8 * g + 2 * q + 1];
+      const h2v a = __builtin_convertvector((f2){x0, x1}, h2v);
+      const h2v c = __builtin_convertvector((f2){__builtin_fmaf((float)a[0], -1.0f, x0), __builtin_fmaf((float)a[1], -1.0f, x1)}, h2v);   // (v_fma_mix_f32: the fp16 piece is read in place)
+      w1[q] = __builtin_bit_cast(uint32_t, a);
+      w2[q] = __builtin_bit_cast(uint32_t, c);
+    }
+    p1[g] = __builtin_bit_cast(h8, w1);
+    p2[g] = __builtin_bit_cast(h8, w2);
+  }
+}
+__device__ __forceinline__ void pack16(const f32x16& v, h8 (&p)[2]) {     // fp32 registers that hold fp16 values exactly
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    u32x4 w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){v[8 * g + 2 * q], v[8 * g + 2 * q + 1]}, h2v));
+    p[g] = __builtin_bit_cast(h8, w);
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                       const float* __restrict__ lse, const float* __restrict__ delta,
+                                                       float* __restrict__ dqkv, int heads, int L, float scale) {
+  static_assert(D == 8, "attn_bwd_fused: head dim 8");
+  constexpr int REC = 2 * 2 * 2 * 16;                                  // A-operand records (query / key tile, g, half, m < 16) of one set
+  __shared__ __attribute__((aligned(16))) uint32_t Qp[3 * kTK * 4];   // Q pieces  (bf16x3 A fragments of S)
+  __shared__ __attribute__((aligned(16))) uint32_t Gp[3 * kTK * 4];   // dO pieces (bf16x3 A fragments of dP)
+  __shared__ __attribute__((aligned(16))) _Float16 QA[(REC + 1) * 8]; // fp16 A operands of dK: rows m = d (piece 1), d + 8 (piece 2); + one zero record
+  __shared__ __attribute__((aligned(16))) _Float16 GA[(REC + 1) * 8]; // ... of dV (dO pieces)
+  __shared__ __attribute__((aligned(16))) _Float16 KA[4 * (REC + 1) * 8];   // ... of dQ: this wave's K pieces (per wave)
+  __shared__ __attribute__((aligned(16))) bf8 Bf[4][2][2][3][64];     // bf16x3 B fragments of the wave's key tiles: K (scaled), V
+  __shared__ __attribute__((aligned(16))) float Ls[kTK];
+  __shared__ __attribute__((aligned(16))) float Ds[kTK];
+  __shared__ __attribute__((aligned(16))) float Dw[4][kTK];            // delta x (this wave's dS scale 2^-14)
+  __shared__ float DQ[4][D][kTK];                                      // the waves' dQ partials of one stage
+  __shared__ float wmax[3][4];
+  const int b = blockIdx.y, h = blockIdx.x, C = heads * D;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+  const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
+  const float* kp = qp + (long)C * L;
+  const float* vp = kp + (long)C * L;
+  const float* gp = d_o + ((long)b * C + h * D) * L;
+  const float* lp = lse + ((long)b * heads + h) * L;
+  const float* dlp = delta + ((long)b * heads + h) * L;
+  float* dqg = dqkv + ((long)b * 3 * C + h * D) * L;
+
+  // zero records (rows m >= 16 of every A operand) and the selection matrices of the transposition:
+  // Perm[g]: k-slot (half, j) selects column n = acc_row(8 g + j, half)
+  if (threadIdx.x < 8) { QA[REC * 8 + threadIdx.x] = (_Float16)0.f; GA[REC * 8 + threadIdx.x] = (_Float16)0.f; }
+  if (threadIdx.x < 32) KA[(threadIdx.x >> 3) * (REC + 1) * 8 + REC * 8 + (threadIdx.x & 7)] = (_Float16)0.f;
+  h8 perm[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) perm[g][j] = (l31 == acc_row(8 * g + j, half)) ? (_Float16)1.0f : (_Float16)0.0f;
+  // A-operand record of this lane for (tile t, group g): rows m >= 16 read the zero record
+  auto a_rec = [&](int t, int g) { return l31 < 16 ? ((t * 2 + g) * 2 + half) * 16 + l31 : REC; };
+  // where a staged row's elements go: row rr = 32 t + rho, rho = (r & 3) + 8 (r >> 2) + 4 half' -> k-slot (half', r & 7) of group r >> 3
+  const int jp0 = threadIdx.x >> 6, rr = threadIdx.x & 63;
+  const int rho = rr & 31, sh = (rho >> 2) & 1, sr = (rho & 3) + 4 * (rho >> 3);
+  const int sbase = ((((rr >> 5) * 2 + (sr >> 3)) * 2 + sh) * 16) * 8 + (sr & 7);         // + m * 8, m = d or d + 8
+
+  float sq = __uint_as_float(kH2ScaleCapBits), sg = sq;                // running scales of Q and dO (workgroup)
+  for (int kb = 0; kb < L; kb += 256) {
+    const int key0 = kb + wv * 64;
+    // ---- this wave's keys: bf16x3 B fragments (K scaled for the log2-domain scores, V), fp16 A operand of dQ (raw K), |V|_1
+    float v1 = 0.f, kmax = 0.f;
+    float xk[2][D];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float xs[D], xv[D];
+      float n1 = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        xk[j][d] = kp[(long)d * L + key0 + j * 32 + l31];
+        xs[d] = xk[j][d] * (scale * kLog2e);
+        xv[d] = vp[(long)d * L + key0 + j * 32 + l31];
+        n1 += fabsf(xv[d]); kmax = fmaxf(kmax, fabsf(xk[j][d]));
+      }
+      v1 = fmaxf(v1, n1);
+      bf8 t[3];
+      row_frags<D>(xs, half, t);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) Bf[wv][j][0][m][lane] = t[m];
+      row_frags<D>(xv, half, t);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) Bf[wv][j][1][m][lane] = t[m];
+    }
+    v1 = wave_amax(v1);
+    const float sk = h2_scale_for(wave_amax(kmax));                    // this wave's K scale for the block
+    if (half == 0) {                                                   // key l31 of tile j: k-slot as above
+      const int kh = (l31 >> 2) & 1, kr = (l31 & 3) + 4 * (l31 >> 3);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          _Float16 a, c;
+          h2_split(xk[j][d], sk, a, c);
+          const int base = wv * (REC + 1) * 8 + (((j * 2 + (kr >> 3)) * 2 + kh) * 16) * 8 + (kr & 7);
+          KA[base + d * 8] = a; KA[base + (d + 8) * 8] = c;
+        }
+    }
+    f32x16 accV[2], accK[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accV[j][r] = 0.f; accK[j][r] = 0.f; }
+    float sds = __uint_as_float(kH2ScaleCapBits);                      // this wave's running scale of dS
+
+    float qreg[2], greg[2], lreg = 0.f, dreg = 0.f;
+    auto fetch = [&](int t0) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        qreg[hh] = qp[(long)(2 * jp0 + hh) * L + t0 + rr];
+        greg[hh] = gp[(long)(2 * jp0 + hh) * L + t0 + rr];
+      }
+      if (threadIdx.x < kTK) { lreg = lp[t0 + threadIdx.x] * kLog2e; dreg = dlp[t0 + threadIdx.x]; }
+    };
+    // the four waves' dQ partials of the stage that ended: added in wave order, into global memory (first key block: stored)
+    auto dq_flush = [&](int t0) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int d = threadIdx.x >> 5, q = (threadIdx.x & 31) + 32 * it;
+        const float t = ((DQ[0][d][q] + DQ[1][d][q]) + DQ[2][d][q]) + DQ[3][d][q];
+        float* dst = dqg + (long)d * L + t0 + q;
+        *dst = kb == 0 ? t : *dst + t;
+      }
+    };
+    fetch(0);
+    for (int t0 = 0; t0 < L; t0 += kTK) {
+      {
+        const float mq = wave_amax(fmaxf(fabsf(qreg[0]), fabsf(qreg[1])));
+        const float mg = wave_amax(fmaxf(fabsf(greg[0]), fabsf(greg[1])));
+        const float md = wave_amax(fabsf(dreg));                       // (threads >= 64 hold 0)
+        if (lane == 0) { wmax[0][wv] = mq; wmax[1][wv] = mg; wmax[2][wv] = md; }
+      }
+      __syncthreads();                                                 // A: the previous stage's reads are done, its dQ partials and the maxima visible
+      const float mq = fmaxf(fmaxf(wmax[0][0], wmax[0][1]), fmaxf(wmax[0][2], wmax[0][3]));
+      const float mg = fmaxf(fmaxf(wmax[1][0], wmax[1][1]), fmaxf(wmax[1][2], wmax[1][3]));
+      const float md = fmaxf(fmaxf(wmax[2][0], wmax[2][1]), fmaxf(wmax[2][2], wmax[2][3]));
+      {
+        const float sqn = fminf(sq, h2_scale_for(mq)), sgn = fminf(sg, h2_scale_for(mg));
+        const float sdn = fminf(sds, h2_scale_for(fmaf(v1, mg, md)));  // |dS| <= |V|_1 max|dO| + max|delta|
+        const float fk = (sqn * h2_inv_pow2(sq)) * (sdn * h2_inv_pow2(sds)), fv = sgn * h2_inv_pow2(sg);
+        if (fk != 1.0f || fv != 1.0f) {                                // (uniform per wave)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { accK[j][r] *= fk; accV[j][r] *= fv; }
+        }
+        sq = sqn; sg = sgn; sds = sdn;
+      }
+      stage_pieces<D>(Qp, rr, jp0, qreg[0], qreg[1]);
+      stage_pieces<D>(Gp, rr, jp0, greg[0], greg[1]);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        _Float16 a, c;
+        h2_split(qreg[hh], sq, a, c);
+        QA[sbase + (2 * jp0 + hh) * 8] = a; QA[sbase + (2 * jp0 + hh + 8) * 8] = c;
+        h2_split(greg[hh], sg, a, c);
+        GA[sbase + (2 * jp0 + hh) * 8] = a; GA[sbase + (2 * jp0 + hh + 8) * 8] = c;
+      }
+      // dS' = P' (dP - delta) s_ds 2^-14 = P' fma(dP, c, -delta c): the rows carry lse log2(e) - 14 (P' = 2^14 P) and delta c.
+      // Every wave has ITS OWN c (its dS scale follows its keys' |V|_1), so the delta rows are kept per wave.
+      const float cds = sds * (1.0f / 16384.0f);
+      if (threadIdx.x < kTK) Ls[threadIdx.x] = lreg - 14.0f;
+      if (t0 > 0) dq_flush(t0 - kTK);
+      if (threadIdx.x < kTK) Ds[threadIdx.x] = dreg;
+      __syncthreads();                                                 // B
+      Dw[wv][lane] = Ds[lane] * cds;                                   // (wave-private: in-order LDS, no barrier)
+      if (t0 + kTK < L) fetch(t0 + kTK);
+      const float udq = (scale * h2_inv_pow2(sds)) * h2_inv_pow2(sk);  // dQ partials leave unscaled
+#pragma unroll
+      for (int qt = 0; qt < kTK / 32; ++qt) {
+        const h8* qa = reinterpret_cast<const h8*>(QA);
+        const h8* ga = reinterpret_cast<const h8*>(GA);
+        const h8* ka = reinterpret_cast<const h8*>(KA) + wv * (REC + 1);
+        f32x16 accQ;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accQ[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // (operands are fetched from LDS right where they are used: the accumulators of five products leave few registers)
+          f32x16 sc, dp;
+          {
+            bf8 aq[3], bkj[3];
+            load_frags<D>(Qp, qt * 32 + l31, half, aq);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) bkj[m] = Bf[wv][j][0][m][lane];
+            sc = dotx3<D>(aq, bkj);
+          }
+          {
+            bf8 ag[3], bvj[3];
+            load_frags<D>(Gp, qt * 32 + l31, half, ag);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) bvj[m] = Bf[wv][j][1][m][lane];
+            dp = dotx3<D>(ag, bvj);
+          }
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {                             // registers 4 r4 .. 4 r4 + 3 are four consecutive query rows
+            const int qr = qt * 32 + 8 * r4 + 4 * half;
+            const float4 ls = *reinterpret_cast<const float4*>(Ls + qr), dl = *reinterpret_cast<const float4*>(&Dw[wv][qr]);
+            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int r = 4 * r4 + i;
+              const float pv = __builtin_amdgcn_exp2f(sc[r] - lsv[i]);                    // P' = 2^14 P
+              sc[r] = pv;
+              dp[r] = pv * __builtin_fmaf(dp[r], cds, -dlv[i]);                           // dS'
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          h8 p1[2], p2[2];
+          {
+            split16(sc, p1, p2);
+            const h8 ga0 = ga[a_rec(qt, 0)], ga1 = ga[a_rec(qt, 1)];
+            __builtin_amdgcn_s_setprio(2);                             // matrix-pipe phases issue ahead of the other wave's vector work
+            accV[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga0, p1[0], accV[j], 0, 0, 0);
+            accV[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga1, p1[1], accV[j], 0, 0, 0);
+            accV[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga0, p2[0], accV[j], 0, 0, 0);
+            accV[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga1, p2[1], accV[j], 0, 0, 0);
+          }
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            split16(dp, p1, p2);
+            const h8 qa0 = qa[a_rec(qt, 0)], qa1 = qa[a_rec(qt, 1)];
+            __builtin_amdgcn_s_setprio(2);
+            accK[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa0, p1[0], accK[j], 0, 0, 0);
+            accK[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa1, p1[1], accK[j], 0, 0, 0);
+            accK[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa0, p2[0], accK[j], 0, 0, 0);
+            accK[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa1, p2[1], accK[j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // the dS' pieces again, now with lane = query, registers = keys: the tile read as an A operand times the selection
+          // matrices (exact: one non-zero product per output), one piece at a time
+          const h8 ka0 = ka[a_rec(j, 0)], ka1 = ka[a_rec(j, 1)];
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) {
+            f32x16 t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = 0.f;
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(pc ? p2[0] : p1[0], perm[0], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(pc ? p2[1] : p1[1], perm[1], t, 0, 0, 0);
+            h8 e[2];
+            pack16(t, e);
+            accQ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka0, e[0], accQ, 0, 0, 0);
+            accQ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka1, e[1], accQ, 0, 0, 0);
+          }
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) DQ[wv][4 * half + i][qt * 32 + l31] = (accQ[i] + accQ[4 + i]) * udq;
+      }
+    }
+    __syncthreads();                                                   // the last stage's dQ partials
+    dq_flush(L - kTK);
+    // ---- dK, dV of this key block: lane (key, half) holds d = 4 half .. 4 half + 3
+    {
+      const float uk = (scale * h2_inv_pow2(sds)) * h2_inv_pow2(sq), uv = h2_inv_pow2(sg) * (1.0f / 16384.0f);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ki = key0 + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          dqkv[((long)b * 3 * C + C + h * D + 4 * half + i) * L + ki] = (accK[j][i] + accK[j][4 + i]) * uk;
+          dqkv[((long)b * 3 * C + 2 * C + h * D + 4 * half + i) * L + ki] = (accV[j][i] + accV[j][4 + i]) * uv;
+        }
+      }
+    }
+    __syncthreads();                                                   // DQ and the wave-resident images are free for the next key block
+  }
+}
+
 // A one-pass backward (S, dP, the exponentials and dS computed once, P and dS transposed through wave-private LDS so that
 // dK / dV become in-lane sums) was built and measured in round 1: register-bound (the loop-invariant Q / dO rows take
 // ~250 registers, or spill), 2.7-13x slower than the two passes above.  It was removed in round 2; the numbers are in
@@ -596,6 +913,15 @@ void attn_mfma8_bwd_dq(const float* qkv, const float* o, const float* d_o, const
                        int B, int heads, int d, int L, float sc, hipStream_t s) {
   if (d == 8) hipLaunchKernelGGL((attn_bwd_dq_mfma<8, 2>), dim3(L / 256, heads, B), dim3(256), 0, s, qkv, o, d_o, lse, dqkv, delta, heads, L, sc);
   else hipLaunchKernelGGL((attn_bwd_dq_mfma<16, 1>), dim3(L / 128, heads, B), dim3(256), 0, s, qkv, o, d_o, lse, dqkv, delta, heads, L, sc);
+}
+// the one-pass backward (d = 8): delta first, then the fused kernel -- one workgroup per (batch, head)
+bool attn_fused_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, float* delta, int B, int heads,
+                    int d, int L, float sc, hipStream_t s) {
+  if (d != 8 || !g_attn_pv || L % 256) return false;
+  const long total = (long)B * heads * L;
+  hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, o, d_o, delta, heads, d, L, total);
+  hipLaunchKernelGGL(attn_bwd_fused<8>, dim3(heads, B), dim3(256), 0, s, qkv, d_o, lse, delta, dqkv, heads, L, sc);
+  return true;
 }
 void attn_mfma8_bwd_dkv(const float* qkv, const float* d_o, const float* lse, const float* delta, float* dqkv, int B, int heads, int L,
                         float sc, hipStream_t s) {
