@@ -223,11 +223,28 @@ __global__ __launch_bounds__(256) void silu_linear_dw_k(const float* __restrict_
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = 0.f;
   if (k < K) {
-    for (int b = g; b < B; b += 8) {
-      const float a = silu(temb[(long)b * K + k]);
+    int b = g;
+    for (; b + 24 < B; b += 32) {                                      // four batch rows in flight
+      float a[4], dv[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = temb[(long)(b + 8 * u) * K + k];
+        const float* d = dout + (long)(b + 8 * u) * N + n0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[u][j] = n0 + j < N ? d[j] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float av = silu(a[u]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = fmaf(dv[u][j], av, s[j]);
+      }
+    }
+    for (; b < B; b += 8) {
+      const float av = silu(temb[(long)b * K + k]);
       const float* d = dout + (long)b * N + n0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s[j] = fmaf(n0 + j < N ? d[j] : 0.f, a, s[j]);
+      for (int j = 0; j < 8; ++j) s[j] = fmaf(n0 + j < N ? d[j] : 0.f, av, s[j]);
     }
   }
 #pragma unroll

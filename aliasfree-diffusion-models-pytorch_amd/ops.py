@@ -195,7 +195,7 @@ class _GradMode:
     folds = []            # per side stream: [packed afd_fold_desc bytes, ...] of producers already launched there
     fold_writes = []      # params whose .grad is complete once the queued folds have been launched
     flushes = 0           # flushes since the last fold launch
-    fold_every = 4        # launch the queued folds every this many flushes (and at the join, and when a bucket completes)
+    fold_every = 2        # launch the queued folds every this many flushes (and at the join, and when a bucket completes)
 
 
 def _wrote(*params):
@@ -283,7 +283,7 @@ def flush_wgrads(final=False):
 class inplace_param_grads:
     def __init__(self, side_stream=None, batch=8, on_write=None, fold_hint=None, fold_every=None):
         self.side_stream, self.batch, self.on_write, self.fold_hint = side_stream, batch, on_write, fold_hint
-        self.fold_every = int(os.environ.get("AFD_FOLD_EVERY", 4)) if fold_every is None else fold_every
+        self.fold_every = int(os.environ.get("AFD_FOLD_EVERY", 2)) if fold_every is None else fold_every
 
     def __enter__(self):
         G = _GradMode

@@ -271,7 +271,9 @@ class TrainStep:
             overlap_wgrad = True
         n_side = int(os.environ.get("AFD_WGRAD_STREAMS", 1))                                # side streams (tuning hook)
         self.wgrad_stream = [torch.cuda.Stream() for _ in range(max(1, n_side))] if overlap_wgrad else None
-        self.wgrad_batch = 16 if graph else 4                                               # layers per fork (AFD_WGRAD_BATCH overrides, read per step: tuning hook)
+        # layers per fork (AFD_WGRAD_BATCH overrides, read per step: tuning hook).  Round 3, after the convolutions moved to the
+        # fp16 matrix pipe (tools/ab_env.py AFD_WGRAD_BATCH, same box): 2 / 4 / 8 / 12 / 16 -> 7.49 / 7.46 / 7.32 / 7.34 / 7.34 ms
+        self.wgrad_batch = 16 if graph else 8
         self.opt = FusedAdamW(model, lr=lr)
         want_ddp = distributed if distributed is not None else dist.is_initialized()
         self.ddp = GradAllReduce(self.opt.fp, n_buckets, model=model) if want_ddp else None

@@ -180,7 +180,7 @@ def kernel_table(dev, B, mode="train"):
         e = float(B) * C * S * S
         add("groupnorm1_fwd_full", tf, bytes_=8 * e, bound="hbm")
         if train:
-            add("groupnorm1_bwd_full", tb, bytes_=20 * e, launches=2, bound="hbm")          # plane sums (x, dy) + apply (x, dy -> dx)
+            add("groupnorm1_bwd_full", tb, bytes_=12 * e, launches=1, bound="hbm")          # sample-resident: x, dy read once, dx written (+ the small partials)
     # ---- block-level filtered resampling (F2 / F3) and the concat copy --------------------------------------------
     for (C, S) in RESAMPLE:
         x = torch.randn(B, C, S, S, device=dev); y = torch.empty(B, C, S // 2, S // 2, device=dev)
