@@ -563,11 +563,7 @@ static void wgrad_bf3_launch_t(const float* x, const float* dy, float* part, int
                                hipStream_t s) {
   using G = BwGeo<S, BN, BK>;
   const size_t lds = std::max((size_t)3 * G::PIECE * 16, G::NSG > 1 ? sizeof(float) * G::NR * 72 * 64 : (size_t)0);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf3<S, BN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  (void)lds_opt_in(&wgrad_bf3<S, BN, BK>, lds);                    // (> 64 KB of dynamic LDS: once per device and kernel)
   hipLaunchKernelGGL((wgrad_bf3<S, BN, BK>), dim3((unsigned)splits, (unsigned)((Cout / BN) * (Cin / BK))), dim3(512), lds, s, x, dy,
                      part, B, Cin, Cout, tps, nt);
 }
@@ -577,11 +573,7 @@ static void wgrad_bf3_s4_launch_t(const float* x, const float* dy, float* part, 
                                   hipStream_t s) {
   constexpr int NR = (BN / 16) * (BK / 32);
   const size_t lds = std::max((size_t)3 * (BK / 16) * 40 * 16 * 16, 8 / NR > 1 ? sizeof(float) * NR * 72 * 64 : (size_t)0);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf3_s4<BN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  (void)lds_opt_in(&wgrad_bf3_s4<BN, BK>, lds);                    // (> 64 KB of dynamic LDS: once per device and kernel)
   hipLaunchKernelGGL((wgrad_bf3_s4<BN, BK>), dim3((unsigned)splits, (unsigned)((Cout / BN) * (Cin / BK))), dim3(512), lds, s, x, dy, part, B,
                      Cin, Cout, tps, nt);
 }

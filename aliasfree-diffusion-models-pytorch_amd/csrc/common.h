@@ -20,6 +20,13 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(afd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Kernels that need more than 64 KB of dynamic LDS opt in through hipFuncSetAttribute -- once per (DEVICE, kernel): the
+// attribute belongs to the device's copy of the function, so a process that drives several GPUs must set it on each.
+int lds_opt_in_impl(const void* kern, size_t lds);   // host.cpp
+template <class K> inline int lds_opt_in(K kern, size_t lds) {
+  return lds <= 64 * 1024 ? AFD_OK : lds_opt_in_impl(reinterpret_cast<const void*>(kern), lds);
+}
+
 constexpr int kWave = 64;                  // CDNA wavefront
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 constexpr float kInvSqrt2Pi = 0.39894228040143267794f;

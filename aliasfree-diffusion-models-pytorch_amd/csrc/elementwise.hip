@@ -188,6 +188,21 @@ __global__ void silu_linear_fwd_batched_k(const float* __restrict__ temb, SiluBa
   s = wave_sum(s);
   if (lane == 0) d.out[i][(long)b * d.N[i] + n] = s + (d.bias[i] ? d.bias[i][n] : 0.f);
 }
+// out_i[b][:] = table_i[clamp(idx[b])][:] for up to 8 tables that share idx (the six stages' time-embedding tables of a
+// sampling run: every timestep's emb_layer output is computed once per trajectory, a denoise step only gathers its rows)
+__global__ void gather_rows_batched_k(const int64_t* __restrict__ idx, SiluBatch d, int B, int rows) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int NT = d.first[d.n];
+  if (i >= (long)B * NT) return;
+  const int b = i / NT, col = i % NT;
+  int l = 0;
+#pragma unroll
+  for (int j = 1; j < 8; ++j) if (j < d.n && col >= d.first[j]) l = j;
+  const int n = col - d.first[l];
+  long r = idx[b];
+  r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
+  d.out[l][(long)b * d.N[l] + n] = d.w[l][r * d.N[l] + n];
+}
 // dw[n,k] = sum_b dout[b,n] silu(temb[b,k]).  Block = EIGHT output rows n x 32 columns k x 8 batch groups: a thread evaluates
 // silu(temb[b,k]) once per batch row and feeds eight running sums (the eight dout values of a row are one broadcast 32-byte
 // read); the 8 batch groups' partial sums meet in LDS (fixed order).  (One row per block, the first form, spent 20 us per
@@ -424,6 +439,19 @@ int afd_silu_linear_fwd_batched(const float* temb, const afd_silu_desc* descs, i
   const long waves = (long)B * d.first[n];
   hipLaunchKernelGGL(silu_linear_fwd_batched_k, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(st), temb, d, B, K);
   return check_launch("afd_silu_linear_fwd_batched");
+}
+int afd_gather_rows_batched(const int64_t* idx, const afd_silu_desc* descs, int n, int B, int rows, afd_stream_t st) {
+  AFD_REQUIRE(idx && descs && n > 0 && n <= 8 && B > 0 && rows > 0, "afd_gather_rows_batched: bad argument (1..8 tables)");
+  SiluBatch d{};
+  d.n = n; d.first[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    AFD_REQUIRE(descs[i].w && descs[i].out && descs[i].N > 0, "afd_gather_rows_batched: bad descriptor %d", i);
+    d.w[i] = descs[i].w; d.bias[i] = nullptr; d.out[i] = descs[i].out; d.N[i] = descs[i].N;
+    d.first[i + 1] = d.first[i] + descs[i].N;
+  }
+  const long total = (long)B * d.first[n];
+  hipLaunchKernelGGL(gather_rows_batched_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(st), idx, d, B, rows);
+  return check_launch("afd_gather_rows_batched");
 }
 int afd_silu_linear_bwd(const float* temb, const float* w, const float* dout, float* dw, float* dbias, float* dtemb,
                         int B, int K, int N, int accumulate, afd_stream_t st) {

@@ -3,6 +3,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 #include <hip/hip_runtime_api.h>
 #include "../../include/afd.h"
@@ -15,6 +18,19 @@ int set_error(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+// (device, kernel) pairs whose dynamic-LDS limit has been raised (common.h: lds_opt_in)
+int lds_opt_in_impl(const void* kern, size_t lds) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({dev, kern})) return AFD_OK;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return set_error(AFD_ELAUNCH, "hipFuncSetAttribute(%zu B of LDS): %s", lds, hipGetErrorString(e));
+  done.insert({dev, kern});
+  return AFD_OK;
 }
 }  // namespace afd
 

@@ -816,20 +816,8 @@ static size_t chain_lds(int C, int nvec) {
   const int nslot = C > 64 ? 2 : 3;
   return sizeof(float) * ((size_t)nslot * C * (C + 4) + (size_t)nvec * C);
 }
-// kernels that need more than 64 KB of dynamic LDS opt in once (per kernel, per process)
-template <class K>
-static int set_lds(K kern, size_t lds) {
-  if (lds <= 64 * 1024) return AFD_OK;
-  static std::mutex mu;
-  static std::set<const void*> done;
-  const void* key = reinterpret_cast<const void*>(kern);
-  std::lock_guard<std::mutex> lock(mu);
-  if (done.count(key)) return AFD_OK;
-  hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return set_error(AFD_ELAUNCH, "hipFuncSetAttribute(%zu B of LDS): %s", lds, hipGetErrorString(e));
-  done.insert(key);
-  return AFD_OK;
-}
+// kernels that need more than 64 KB of dynamic LDS opt in once per (device, kernel): common.h lds_opt_in
+template <class K> static int set_lds(K kern, size_t lds) { return lds_opt_in(kern, lds); }
 static int g_tok_max_wg = 0;       // test hook (afd_debug_tok_grid): cap on the workgroups of a launch, 0 = by the rule
 static int g_tok_path = 0;         // test hook (afd_debug_tok_path): 0 = by the rule, 1 = never the wide forms, 2 = wide wherever they exist
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -552,11 +552,7 @@ static void wino_launch_t(const float* x, const float* U, const float* bias, con
                           hipStream_t s) {
   using G = WGeo<GEO, NT>;
   const size_t lds = 2 * sizeof(float) * (16 * BN * 10 + 8 * G::RSP);   // two stages
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<GEO, BN, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  (void)lds_opt_in(&conv_wino<GEO, BN, NT>, lds);                    // (> 64 KB of dynamic LDS: once per device and kernel)
   const int tg = G::TI == 1 ? B * G::GPI : (B + G::TI - 1) / G::TI;
   const int items = tg * (N / BN);
   // persistent grid: as many workgroups as fit the chip at once (8-wave groups: one per CU, smaller ones: two), each
@@ -847,11 +843,7 @@ static void wgrad_wino_launch_t(const float* x, const float* dy, float* part, in
                                 hipStream_t s) {
   using Q = WgGeo<S>;
   const size_t lds = sizeof(float) * ((size_t)BK * Q::RSX + (size_t)BN * Q::DS);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino<S, BN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  (void)lds_opt_in(&wgrad_wino<S, BN, BK>, lds);                    // (> 64 KB of dynamic LDS: once per device and kernel)
   hipLaunchKernelGGL((wgrad_wino<S, BN, BK>), dim3(Cout / BN, Cin / BK, splits), dim3((BN / 32) * (BK / 16) * 64), lds, s,
                      x, dy, part, B, Cin, Cout, cps, nch);
 }

@@ -107,6 +107,7 @@ class Diffusion:
         theta_step = None if theta is None else theta / self.noise_steps
         if graph is None:
             graph = False
+        self._hint(model)
         model.eval()
         snaps = []
         with torch.no_grad():
@@ -133,8 +134,22 @@ class Diffusion:
                 if i % 100 == 0:
                     snaps.append(x)
         model.train()        # the reference leaves the model in train mode (:379)
+        self._unhint(model)
         snaps.append(x)
         return x, snaps
+
+    def _hint(self, model):
+        """Tell the model the range of the timesteps this process will pass (all of them in [0, noise_steps)): lets the
+        UNet tabulate its time embeddings once per trajectory (unet.UNet._timestep_tables); cleared again when the loop
+        ends (_unhint), so a direct call of the model may pass any t."""
+        if hasattr(model, "_t_range"):
+            model._t_range = self.noise_steps
+
+    @staticmethod
+    def _unhint(model):
+        """The loop is over: a later direct call of the model may pass any t again."""
+        if hasattr(model, "_t_range"):
+            model._t_range = None
 
     def _graph_steps(self, model, x, snaps):
         """Steps i = T-1 .. 2 by replaying one captured step; returns x after step 2."""
@@ -237,6 +252,7 @@ class Diffusion:
         K = len(thetas)
         if K == 0:                                       # (a rank of the sharded sweep that holds no angle)
             return [], []
+        self._hint(model)
         model.eval()
         snaps = [[] for _ in range(K)]
         with torch.no_grad():
@@ -252,6 +268,7 @@ class Diffusion:
                     for k in range(K):
                         snaps[k].append(x[k * n:(k + 1) * n].clone())
         model.train()
+        self._unhint(model)
         xs, results = [], []
         for k in range(K):
             xk = x[k * n:(k + 1) * n]
@@ -269,6 +286,7 @@ class Diffusion:
         graph=True: every trajectory's denoise step (UNet forward + update; the noise is drawn into a static buffer just
         before) is captured once into its own hipGraph and replayed on its stream, which takes the host's ~170 launches
         per forward out of the loop."""
+        self._hint(model)
         model.eval()
         if graph:
             return self._sample_concurrent_graphs(model, n, image_channels, batch, streams, noise_fn)
@@ -303,6 +321,7 @@ class Diffusion:
                         snaps_out[k] = ops.quantize_u8(torch.cat(snaps[k]))
                     cur.wait_stream(pool[k - g0])
         model.train()
+        self._unhint(model)
         for t in xs_out + snaps_out:
             t.record_stream(cur)
         return torch.cat(xs_out), torch.cat(snaps_out)
@@ -364,6 +383,7 @@ class Diffusion:
                         snaps_out[k] = ops.quantize_u8(torch.cat(snaps[k] + [xs]))
                     cur.wait_stream(pool[k - g0])
         model.train()
+        self._unhint(model)
         for t in xs_out + snaps_out:
             t.record_stream(cur)
         return torch.cat(xs_out), torch.cat(snaps_out)
@@ -382,6 +402,7 @@ class Diffusion:
         if shift is not None:
             dur = np.abs(shift) / self.noise_steps
             idx = set(np.round(np.arange(0, self.noise_steps, dur)).astype(int)[1:].tolist())
+        self._hint(model)
         model.eval()
         with torch.no_grad():
             x = self._initial_noise(n, image_channels, noise_source)
@@ -392,6 +413,7 @@ class Diffusion:
                 if idx is not None and i in idx:
                     x = self.shift_2d_matrix(x, 1 * np.sign(shift), 0, self.device)
         model.train()
+        self._unhint(model)
         return ops.quantize_u8(x)
 
     # F17 (Config E): the reference rotates on the CPU with scipy every step (D2H, single-threaded spline,

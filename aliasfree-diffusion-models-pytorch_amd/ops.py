@@ -531,8 +531,12 @@ class WinoStepPlan:
 
 
 def bump_param_epoch():
-    """Call after parameters were modified through raw device pointers (the fused optimizer)."""
+    """Call after parameters were modified through raw device pointers (the fused optimizer).  Every cached weight image is
+    stale from here on: the store is emptied (each buffer goes back to the pool of the one stream that used it), so a
+    sampling run after training does not pin images of streams that no longer exist."""
     _WinoWeights.epoch += 1
+    if _WinoWeights.store:
+        _WinoWeights.store.clear()
 
 
 def _conv_fwd(x, w, bias, res, y, B, Cin, Cout, H, W, ks, act, want_dgrad=False):
@@ -1044,6 +1048,18 @@ def silu_linear_batched(temb, layers):
     desc = b"".join(struct.pack("<QQQi4x", _p(w) or 0, _p(b) or 0, _p(o), w.shape[0]) for w, b, o in zip(ws, bs, outs))
     buf = ctypes.create_string_buffer(desc, len(desc))
     lib().afd_silu_linear_fwd_batched(_p(temb), ctypes.addressof(buf), len(ws), B, K, _stream())
+    return outs
+
+
+def gather_rows_batched(idx, tables):
+    """[table_i[idx] for table_i in tables] in one launch (idx (B,) int64 on the device; tables (rows, N_i) fp32)."""
+    import ctypes, struct
+    _chk(*tables)
+    B, rows = idx.shape[0], tables[0].shape[0]
+    outs = [torch.empty(B, t.shape[1], device=t.device, dtype=torch.float32) for t in tables]
+    desc = b"".join(struct.pack("<QQQi4x", _p(t), 0, _p(o), t.shape[1]) for t, o in zip(tables, outs))
+    buf = ctypes.create_string_buffer(desc, len(desc))
+    lib().afd_gather_rows_batched(_p(idx), ctypes.addressof(buf), len(tables), B, rows, _stream())
     return outs
 
 

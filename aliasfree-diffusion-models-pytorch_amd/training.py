@@ -53,11 +53,19 @@ class FlatParams:
     must see neither the update nor the weight decay.  state_dict()/load_state_dict() keep working (the Parameters are
     the same objects; only their storage moved)."""
 
-    def __init__(self, model):
+    def __init__(self, model, conditional=False):
+        """conditional: the train loop will pass class labels (UNet.forward(x, t, y)), so `label_emb` is a live parameter
+        (updated and exchanged); the reference's own loop never does (ddpm_utils.py:502), hence the default."""
         params = [p for p in model.parameters()]
         assert params and all(p.dtype == torch.float32 for p in params)
         unused = getattr(model, "unused_parameters", None)
-        skip = {id(p) for p in unused()} if callable(unused) else set()
+        skip = set()
+        if callable(unused):
+            try:
+                skip = {id(p) for p in unused(conditional=conditional)}
+            except TypeError:
+                skip = {id(p) for p in unused()}
+        self.conditional = conditional
         params = [p for p in params if id(p) not in skip] + [p for p in params if id(p) in skip]
         dev = params[0].device
         self.params = params
@@ -88,8 +96,8 @@ class FusedAdamW:
     `n_active` elements: see FlatParams).
     The step counter and bias corrections live on the device so a captured hipGraph replays correctly."""
 
-    def __init__(self, model_or_flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
-        self.fp = model_or_flat if isinstance(model_or_flat, FlatParams) else FlatParams(model_or_flat)
+    def __init__(self, model_or_flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, conditional=False):
+        self.fp = model_or_flat if isinstance(model_or_flat, FlatParams) else FlatParams(model_or_flat, conditional=conditional)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         dev = self.fp.flat.device
         self.m = torch.zeros_like(self.fp.flat)
@@ -260,8 +268,12 @@ class TrainStep:
     (one 23.6 MB exchange) and AdamW then run after the replay.  The CPU-generator timestep draw and the
     H2D copies always stay outside the graph."""
 
-    def __init__(self, model, diffusion, lr, graph=False, distributed=None, n_buckets=4, overlap_wgrad=None):
+    def __init__(self, model, diffusion, lr, graph=False, distributed=None, n_buckets=4, overlap_wgrad=None, conditional=False):
+        """conditional=True: the step takes class labels (`step(images, y=labels)`, UNet.forward(x, t, y): ddpm_models.py:276-277)
+        and `label_emb` is optimised and exchanged like every other parameter.  With the default (the reference's loop,
+        ddpm_utils.py:502, never passes labels) `label_emb` stays untouched, as under the reference's AdamW, and passing y raises."""
         self.model, self.diffusion = model, diffusion
+        self.conditional = conditional
         # weight-gradient kernels on a second stream (ops._GradMode.side): off the critical path of backward, they fill
         # the CUs the dependent chain of small kernels leaves idle.  Measured on MI355X (B=256): eager 12.0 -> 11.1
         # ms/step, captured graph 11.45 -> 11.3 (forks batched 16 layers at a time: every fork is a cross-stream edge
@@ -274,7 +286,7 @@ class TrainStep:
         # layers per fork (AFD_WGRAD_BATCH overrides, read per step: tuning hook).  Round 3, after the convolutions moved to the
         # fp16 matrix pipe (tools/ab_env.py AFD_WGRAD_BATCH, same box): 2 / 4 / 8 / 12 / 16 -> 7.49 / 7.46 / 7.32 / 7.34 / 7.34 ms
         self.wgrad_batch = 16 if graph else 8
-        self.opt = FusedAdamW(model, lr=lr)
+        self.opt = FusedAdamW(model, lr=lr, conditional=conditional)
         want_ddp = distributed if distributed is not None else dist.is_initialized()
         self.ddp = GradAllReduce(self.opt.fp, n_buckets, model=model) if want_ddp else None
         if self.ddp is not None:
@@ -285,7 +297,7 @@ class TrainStep:
         self._static = None
         self._wino_plan, self._wino_requests = None, None      # ops.WinoStepPlan after the first (recording) step
 
-    def _fwd_bwd(self, images, t, eps):
+    def _fwd_bwd(self, images, t, eps, y=None):
         W = ops._WinoWeights
         if self._wino_plan is not None and self._wino_plan.valid():
             self._wino_plan.launch()                   # every transformed-weight image of the step, one launch
@@ -294,7 +306,7 @@ class TrainStep:
             self._wino_requests = W.recording = {}     # first step: note which images the dispatch asks for
         try:
             x_t, noise = self.diffusion.noise_images(images, t, eps)
-            pred = self.model(x_t, t)
+            pred = self.model(x_t, t) if y is None else self.model(x_t, t, y)
             loss = ops.mse_loss(noise, pred)
             self.opt.zero_grad()
             overlap = self.ddp is not None and self.ddp.world > 1 and not self.use_graph      # (a captured backward cannot hold the exchange)
@@ -317,19 +329,25 @@ class TrainStep:
         scale = self.ddp.finish() if self.ddp is not None else 1.0
         self.opt.step(grad_scale=scale)
 
-    def _body(self, images, t, eps):
-        loss = self._fwd_bwd(images, t, eps)
+    def _body(self, images, t, eps, y=None):
+        loss = self._fwd_bwd(images, t, eps, y)
         self._update()
         return loss
 
-    def __call__(self, images, t=None, eps=None):
+    def __call__(self, images, t=None, eps=None, y=None):
         """images (B,C,S,S) on the device; t (B,) int64 [default: diffusion.sample_timesteps];
-        eps: injected noise or None (device RNG).  Returns the loss as a 0-d device tensor."""
+        eps: injected noise or None (device RNG); y (B,) int64 class labels (only with conditional=True, eager launches).
+        Returns the loss as a 0-d device tensor."""
+        if y is not None and not self.conditional:
+            raise ValueError("TrainStep: class labels were passed but the step was built with conditional=False: label_emb sits "
+                             "outside the optimised range (FlatParams) and would never be updated; build TrainStep(..., conditional=True)")
+        if y is not None and self.use_graph:
+            raise ValueError("TrainStep(graph=True) does not take class labels; use eager launches for conditional training")
         if t is None:
             t = self.diffusion.sample_timesteps(images.shape[0])
         t = t.to(images.device, non_blocking=True)
         if not self.use_graph:
-            return self._body(images, t, eps)
+            return self._body(images, t, eps, y)
         whole = self.ddp is None                    # single GPU: AdamW is captured too
         if self._graph is None:
             self._static = {"images": images.clone(), "t": t.clone(), "eps": None if eps is None else eps.clone()}

@@ -65,6 +65,8 @@ class UNet(nn.Module):
         else:
             print("Unconditional UNet")
         self._inv_freq = None
+        self._t_range = None        # set by Diffusion around a sampling loop: every t it passes lies in [0, _t_range)
+        self._emb_tables = {}       # HIP stream -> (stamp, [table per stage]): emb_layer(pos_encoding(t)) for t = 0 .. _t_range - 1
 
     def unused_parameters(self, conditional=False):
         """Parameters `forward(x, t)` never touches, so their grad stays None in the reference and its AdamW skips them:
@@ -95,18 +97,44 @@ class UNet(nn.Module):
             tt = tt.long()
         return ops.pos_encoding(tt, self._inv_freq_on(tt.device))
 
+    def _timestep_tables(self, device, layers):
+        """[emb_layer_i(pos_encoding(t)) for t in range(_t_range)] per stage, cached per HIP stream while the parameters do
+        not change (stamped like the cached weight images: ops._WinoWeights)."""
+        key = ops._stream()
+        stamp = (ops._WinoWeights.epoch, self._t_range, tuple((w._version, w.data_ptr(), b._version) for w, b in layers))
+        hit = self._emb_tables.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        tt = torch.arange(self._t_range, device=device, dtype=torch.long)
+        tables = ops.silu_linear_batched(self.pos_encoding(tt, self.time_dim), layers)
+        if len(self._emb_tables) >= 16:
+            self._emb_tables.clear()
+        self._emb_tables[key] = (stamp, tables)
+        return tables
+
     # -- forward ----------------------------------------------------------------------------
     def forward(self, x, t, y=None):
         if not x.is_cuda:
             raise ops.AfdError("afdm.UNet: the HIP engine has no CPU path; move the model and inputs to 'cuda'")
-        t = self.pos_encoding(t.to(x.device), self.time_dim)
-        if y is not None:
-            t = ops.EmbedAdd.apply(t, self.label_emb.weight, y.to(x.device))        # t += label_emb(y)   (:276-277)
-        if not t.requires_grad:                       # the six stages' emb_layer(t) in one launch (t is ready now)
-            stages = (self.down1, self.down2, self.down3, self.up1, self.up2, self.up3)
-            layers = [(s.emb_layer[1].weight, s.emb_layer[1].bias) for s in stages]
-            for s, e in zip(stages, ops.silu_linear_batched(t, layers)):
+        stages = (self.down1, self.down2, self.down3, self.up1, self.up2, self.up3)
+        layers = [(s.emb_layer[1].weight, s.emb_layer[1].bias) for s in stages]
+        t_idx = t.to(x.device)
+        if (y is None and self._t_range and not torch.is_grad_enabled() and t_idx.dtype == torch.long
+                and not torch.cuda.is_current_stream_capturing()):      # (a captured step keeps its own computation: nothing cached may live in a graph's pool)
+            # sampling: the stages' time embeddings depend on the integer timestep only -- tabulated once per trajectory (and
+            # HIP stream) for every timestep, a denoise step gathers its rows (one small launch instead of the positional
+            # encoding + the 448 x 256 matrix-vector products per image: 50 us of a 2.3 ms forward); bit-identical values
+            tables = self._timestep_tables(x.device, layers)
+            t = t_idx                                  # (only its identity is used below)
+            for s, e in zip(stages, ops.gather_rows_batched(t_idx.reshape(-1), tables)):
                 s._emb_pre = (t, e)
+        else:
+            t = self.pos_encoding(t_idx, self.time_dim)
+            if y is not None:
+                t = ops.EmbedAdd.apply(t, self.label_emb.weight, y.to(x.device))        # t += label_emb(y)   (:276-277)
+            if not t.requires_grad:                       # the six stages' emb_layer(t) in one launch (t is ready now)
+                for s, e in zip(stages, ops.silu_linear_batched(t, layers)):
+                    s._emb_pre = (t, e)
         x1 = self.inc(x)
         x2 = self.sa1(self.down1(x1, t))
         x3 = self.sa2(self.down2(x2, t))

@@ -324,6 +324,11 @@ typedef struct afd_silu_desc {
   int N;
 } afd_silu_desc;
 int afd_silu_linear_fwd_batched(const float* temb, const afd_silu_desc* descs, int n, int B, int K, afd_stream_t stream);
+/* out_i[b][:] = table_i[idx[b]][:] (idx clamped to [0, rows)) for up to 8 tables (descs[i].w = table_i (rows, N_i),
+ * descs[i].out = (B, N_i), bias unused) in one launch.  Sampling: emb_layer(pos_encoding(t)) depends on the integer t only,
+ * so the host package tabulates it for every timestep once per trajectory (with the two entry points above) and a denoise
+ * step gathers its rows -- bit-identical to computing them (ddpm_models.py:261-269, ddpm_utils.py:208-214). */
+int afd_gather_rows_batched(const int64_t* idx, const afd_silu_desc* descs, int n, int B, int rows, afd_stream_t stream);
 
 /* label conditioning: out[b, :] = temb[b, :] + table[y[b], :]   (nn.Embedding lookup + add, ddpm_models.py:254,276-277)
  * y: (B,) int64 class indices in [0, num_classes); out may alias temb.

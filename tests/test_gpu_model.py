@@ -683,3 +683,30 @@ def test_bench_entry_point_two_ranks_dry_run(A, tmp_path):
     assert d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
     assert math.isfinite(d["final_loss"]) and d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
     assert d["metric"] == "train_step_images_per_sec" and d["unit"] == "images/s" and d["vs_baseline"] is None
+
+
+def test_conditional_train_step_updates_label_embedding(A):
+    """TrainStep(conditional=True): labels go to UNet.forward(x, t, y) (ddpm_models.py:276-277) and label_emb is inside the
+    optimised / exchanged range; with the default (the reference's loop passes no labels, ddpm_utils.py:502) it stays outside
+    and passing y is refused instead of silently never training the table."""
+    afdm, dev = A
+    afdm.set_seed(42)
+    model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(F_SET), device=dev, variant=3, num_classes=10).to(dev)
+    diff = afdm.Diffusion(noise_steps=1000, img_size=32, device=dev)
+    g = torch.Generator().manual_seed(3)
+    images = (torch.rand(4, 3, 32, 32, generator=g) * 2 - 1).to(dev)
+    y = torch.tensor([1, 7, 7, 3], device=dev)
+    step = afdm.TrainStep(model, diff, lr=3e-4, graph=False, conditional=True)
+    assert step.opt.fp.n_active == step.opt.fp.numel                       # nothing sits outside the optimised range
+    before = model.label_emb.weight.detach().clone()
+    loss = step(images, y=y)
+    assert math.isfinite(loss.item())
+    # AdamW with a dense gradient: every row decays by (1 - lr * wd); the rows of the labels seen also take the Adam step (~lr)
+    decay_only = before * (1 - 3e-4 * 0.01)
+    dev_from_decay = (model.label_emb.weight.detach() - decay_only).abs().max(dim=1).values
+    assert [bool(v > 1e-4) for v in dev_from_decay.tolist()] == [i in (1, 3, 7) for i in range(10)]
+    assert float(dev_from_decay[[0, 2, 4, 5, 6, 8, 9]].max()) < 1e-6
+    step2 = afdm.TrainStep(model, diff, lr=3e-4, graph=False)
+    assert step2.opt.fp.n_active == step2.opt.fp.numel - model.label_emb.weight.numel()
+    with pytest.raises(ValueError, match="conditional=False"):
+        step2(images, y=y)
