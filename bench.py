@@ -265,13 +265,13 @@ def kernel_table(dev, B, mode="train"):
         add("adamw", ev_time(adam), bytes_=28.0 * N_PARAMS, launches=2, bound="hbm")
     else:
         import ctypes, struct
-        ws_ = [torch.randn(C, 256, device=dev) for C in EMB]
-        bs_ = [torch.randn(C, device=dev) for C in EMB]
+        tabs = [torch.randn(1000, C, device=dev) for C in EMB]           # emb_layer(pos_encoding(t)) of every timestep: built once per trajectory
         os_ = [torch.empty(B, C, device=dev) for C in EMB]
-        desc = b"".join(struct.pack("<QQQi4x", P(w), P(b), P(o), w.shape[0]) for w, b, o in zip(ws_, bs_, os_))
+        tix = torch.randint(0, 1000, (B,), device=dev)
+        desc = b"".join(struct.pack("<QQQi4x", P(w), 0, P(o), w.shape[1]) for w, o in zip(tabs, os_))
         buf = ctypes.create_string_buffer(desc, len(desc))
-        add("silu_linear_fwd_batched", ev_time(lambda: L.afd_silu_linear_fwd_batched(P(temb), ctypes.addressof(buf), len(EMB), B, 256, s)),
-            2.0 * B * 256 * sum(EMB), bytes_=4.0 * (B * 256 + (256 + B) * sum(EMB)), bound="hbm")
+        add("timestep_embedding_gather", ev_time(lambda: L.afd_gather_rows_batched(P(tix), ctypes.addressof(buf), len(EMB), B, 1000, s)),
+            bytes_=4.0 * 2 * B * sum(EMB), bound="hbm")
         x32 = torch.randn(B, 32, 32, 32, device=dev); w_out = torch.randn(3, 32, 1, 1, device=dev); b_out = torch.randn(3, device=dev)
         y3 = torch.empty(B, 3, 32, 32, device=dev)
         add("outc_1x1", ev_time(lambda: L.afd_conv_fwd(P(x32), P(w_out), P(b_out), None, P(y3), B, 32, 3, 32, 32, 1, 0, s)), bytes_=4.0 * B * 35 * 1024, bound="hbm")
@@ -308,6 +308,8 @@ def kernel_table(dev, B, mode="train"):
         if name in pmc and pmc[name].get("mfma_busy_frac") is not None:
             # NOT measured by this run: merged from the committed rocprofv3 PMC pass of an earlier profiling run
             row["mfma_busy_pmc_from_profile"] = pmc[name]["mfma_busy_frac"]
+            if pmc[name].get("valu_busy_frac") is not None:
+                row["valu_busy_pmc_from_profile"] = pmc[name]["valu_busy_frac"]
             row["pmc_source"] = pmc[name].get("source", pmc_path)
         out.append(row)
     out.sort(key=lambda z: -z["ms_per_step"])
@@ -378,17 +380,20 @@ def roofline_of(table, rows, pmc_path="profiles/pmc_families.json"):
                     achieved_algorithmic=round(ach_alg, 2), frac_algorithmic_vs_fp32_peak=round(ach_alg / MFMA_F32_PEAK_TF, 4),
                     launches_by_form=trow.get("launches_by_form"), mfma_busy_pmc_from_profile=trow.get("mfma_busy_pmc_from_profile"),
                     pmc_source=trow.get("pmc_source"),
-                    basis="executed: the large layers run the direct form on the bf16 MFMA with exact three-piece splits (6 bf16 products per "
-                          "fp32 product, fp32-class results), the small maps fp32 Winograd (16/36 of the products); achieved = issued products "
-                          "priced at the peak of the instruction that issues them, expressed on the bf16 scale; achieved_algorithmic = "
-                          "direct-form fp32 flops (2*9*Cin*Cout per output pixel, SURVEY 8d) / HIP-event time")
+                    basis="executed: the layers run direct matrix-core kernels on two fp16 pieces per operand under power-of-two scales that follow "
+                          "the data (3 fp16 products per fp32 product, fp32-class results: csrc/h2_common.h; launches_by_form: h2; bf3 = round 2's "
+                          "three-piece bf16 form, 6 products; wino = fp32 Winograd, 16/36 of the products; direct = fp32 MFMA); achieved = issued "
+                          "products priced at the peak of the instruction that issues them, expressed on the fp16 / bf16 scale (2500 TFLOP/s dense); "
+                          "achieved_algorithmic = direct-form fp32 flops (2*9*Cin*Cout per output pixel, SURVEY 8d) / HIP-event time")
     if r["bound"] == "mfma":
         ach = r["flops"] / sec / 1e12
         return dict(common, bound="mfma", achieved=round(ach, 2), peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=round(ach / MFMA_F32_PEAK_TF, 4),
-                    mfma_busy_pmc_from_profile=trow.get("mfma_busy_pmc_from_profile"), pmc_source=trow.get("pmc_source"),
-                    basis="algorithmic attention flops (4*L*L*C forward, 2.5x that backward, SURVEY 8d) / HIP-event time; fp32 results; the "
-                          "d-contractions run as 3-piece bf16 splits on the matrix cores (fp32-exact), the rank-d updates and the softmax on the "
-                          "vector pipe; priced against the fp32 matrix peak")
+                    mfma_busy_pmc_from_profile=trow.get("mfma_busy_pmc_from_profile"), valu_busy_pmc_from_profile=trow.get("valu_busy_pmc_from_profile"),
+                    pmc_source=trow.get("pmc_source"),
+                    basis="algorithmic attention flops (4*L*L*C forward, 2.5x that backward, SURVEY 8d) / HIP-event time, priced against the fp32 "
+                          "matrix peak (fp32-class results).  Executed: S / dP as 3-piece bf16 splits on the matrix cores; at head dim 8 (90 % of the "
+                          "flops) P V, dV, dK, dQ as two-piece fp16 products on the matrix cores too (one-pass backward), the softmax algebra and the "
+                          "splits on the vector pipe, which bounds the kernels (PMC: valu_busy_pmc_from_profile)")
     ach = r["bytes"] / sec / 1e9
     return dict(common, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
 

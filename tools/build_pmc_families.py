@@ -40,7 +40,8 @@ def summarise(pers, div, kernels=None):
     return {"hbm_bytes_per_step": int(2 * fetch + write), "fetch_bytes_raw": int(fetch), "fetch_bytes_x2": int(2 * fetch),
             "write_bytes": int(write), "mfma_insts_per_step": int(tot["SQ_INSTS_MFMA"] / div),
             "valu_insts_per_step": int(tot["SQ_INSTS_VALU"] / div),
-            "mfma_busy_frac": round(tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8 * 1024), 4) if gui else None}
+            "mfma_busy_frac": round(tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8 * 1024), 4) if gui else None,
+            "valu_busy_frac": round(tot["SQ_ACTIVE_INST_VALU"] * 4 / (gui / 8 * 1024), 4) if gui and tot.get("SQ_ACTIVE_INST_VALU") else None}
 
 
 out = {}
