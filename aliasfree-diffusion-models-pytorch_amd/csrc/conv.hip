@@ -817,6 +817,7 @@ void bf3_set_mode(int m);
 void direct_form_set(int m);
 bool direct_form_is_bf3();
 void h2_sk_set_mode(int m);
+void h2_lds_set(int m);
 void wino_weights_batched_launch(const afd_wino_desc* descs, const int* wg_desc, int n_wg, hipStream_t s);
 void wino_set_grid(int g);
 int wgrad_wino_plan(int B, int Cin, int Cout, int H, int W, int* bn, int* bk, int* cps, int* nchunks);
@@ -951,6 +952,7 @@ int afd_debug_conv_path(int mode) {
   if (mode >= 92 && mode <= 93) { ends_set_mode(mode - 92); return AFD_OK; }   // output-layer streaming kernels: 92 = by rule (default), 93 = off
   if (mode >= 88 && mode <= 89) { pw_wgrad_bf3_set_mode(mode - 88); return AFD_OK; }   // bf16x3 1x1 wgrad: 88 = by rule (default), 89 = off
   if (mode >= 84 && mode <= 86) { wgrad_bf3_set_mode(mode - 84); return AFD_OK; }   // bf16x3 3x3 wgrad: 84 = by rule (default), 85 = off, 86 = wherever covered
+  if (mode >= 59 && mode <= 63) { h2_lds_set(mode == 59 ? 4 : (mode == 60 ? 1 : (mode == 61 ? 0 : mode - 60))); return AFD_OK; }   // f16x2 tile kernel: 60 = both operands from LDS, weights by LDS-DMA (default), 61 = the register-fed kernel (before round 3's last third), 62 / 63 / 59 = LDS-fed wherever covered, the (128 px, 64 ch) / (256 px, 32 ch) / (128 px, 32 ch) workgroup first (tests)
   if (mode == 73) { h2_sk_set_mode(2); return AFD_OK; }                          // ... 73 = wherever the shape is covered (tests)
   if (mode >= 74 && mode <= 75) { h2_sk_set_mode(mode - 74); return AFD_OK; }    // f16x2 split-K kernel for the 4x4 / thin 8x8 maps: 74 = by rule (default), 75 = off (round 1's fp32 Winograd split-K kernel)
   if (mode >= 78 && mode <= 79) { wgrad_arith_set(mode - 78); return AFD_OK; }   // arithmetic of the matrix-core 3x3 weight gradient: 78 = f16x2 (default), 79 = bf16x3 (round 2)

@@ -298,7 +298,7 @@ def kernel_table(dev, B, mode="train"):
         if r["bound"] == "mfma" and "pipe_s" in r:
             # executed fraction: matrix-pipe time at the peak of the instruction each launch issues / measured time
             row["frac"] = round(r["pipe_s"] / sec, 4)
-            row["frac_basis"] = "executed: issued products at the peak of the instruction issued (bf16x3 6x on the 2500 TFLOP/s bf16 MFMA; Winograd 16/36 and direct 1x on the 157.3 TFLOP/s fp32 MFMA)"
+            row["frac_basis"] = "executed: issued products at the peak of the instruction issued (f16x2: 3 fp16 products, bf16x3: 6 bf16 products per fp32 product on the 2500 TFLOP/s 16-bit MFMA; Winograd 16/36 and direct 1x on the 157.3 TFLOP/s fp32 MFMA)"
             row["launches_by_form"] = {k: r[k] for k in ("h2", "bf3", "wino", "direct") if r.get(k)}
             row["frac_algorithmic_vs_fp32_peak"] = round(tf / MFMA_F32_PEAK_TF, 4)
         elif r["bound"] == "mfma":

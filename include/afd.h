@@ -136,6 +136,10 @@ int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, in
  * 74 / 75 = the f16x2 split-K kernel for the 4x4 maps and the thin 8x8 launches (csrc/h2.hip conv_h2_sk; also a direct form:
  *           afd_conv3x3_weight_kinds reports it) by rule (default) / never (round 1's fp32 Winograd split-K kernel instead);
  *           73 = wherever the shape is covered, ahead of the tile kernel (tests);
+ * 60 / 61 = the f16x2 tile kernel's operand feed: by rule (default: both operands from LDS, the weights by LDS-DMA, where a
+ *           workgroup holds one block of 32 output channels on the 32 x 32 maps; the weights straight from L2 into registers
+ *           elsewhere) / always the register-fed kernel;  62 / 63 / 59 = the LDS-fed kernel wherever the shape is covered,
+ *           trying its (128 pixels x 64 channels) / (256 x 32) / (128 x 32) workgroup first (tests);
  * 76 / 77 = arithmetic of that direct form: two fp16 pieces under an online power-of-two scale (csrc/h2.hip, default) /
  *           three bf16 pieces (round 2, csrc/bf3.hip);  78 / 79 = the same choice for the matrix-core 3x3 weight gradient
  *           (csrc/h2_wgrad.hip / csrc/bf3_wgrad.hip);

@@ -280,12 +280,14 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "bf3", "nobf3", "h2sk", "wgbf3", "nowgbf3", "noends", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "winosk", "nowino", "wgwino", "nowgwino"])
+@pytest.mark.parametrize("path", ["auto", "big", "splitk", "wgrad4", "wgrad8", "pw", "bf3", "nobf3", "h2reg", "h2l64", "h2l256", "h2l32", "h2sk", "wgbf3", "nowgbf3", "noends", "wino64x64", "wino32x64", "wino64x32", "wino32x32", "winosk", "nowino", "wgwino", "nowgwino"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[f"B{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[5]}" for c in CONV_CASES])
 def test_conv_fwd_dgrad_wgrad(A, case, path):
     afdm, ops, dev = A
-    afdm.lib().afd_debug_conv_path({"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10, "bf3": 82, "nobf3": 81, "h2sk": 73, "wgbf3": 86, "nowgbf3": 85, "noends": 93,
-                                        "wino64x64": 66, "wino32x64": 67, "wino64x32": 68, "wino32x32": 69, "winosk": 70, "nowino": 65, "wgwino": 98, "nowgwino": 97}[path])
+    modes = {"auto": 0, "big": 1, "splitk": 2, "wgrad4": 32, "wgrad8": 33, "pw": 10, "bf3": 82, "nobf3": 81, "h2reg": (82, 61), "h2l64": (82, 62), "h2l256": (82, 63), "h2l32": (82, 59), "h2sk": 73, "wgbf3": 86, "nowgbf3": 85, "noends": 93,
+                                        "wino64x64": 66, "wino32x64": 67, "wino64x32": 68, "wino32x32": 69, "winosk": 70, "nowino": 65, "wgwino": 98, "nowgwino": 97}[path]
+    for m in (modes if isinstance(modes, tuple) else (modes,)):
+        afdm.lib().afd_debug_conv_path(m)
     try:
         _conv_case(ops, dev, case)
     finally:
@@ -293,6 +295,7 @@ def test_conv_fwd_dgrad_wgrad(A, case, path):
         afdm.lib().afd_debug_conv_path(34)
         afdm.lib().afd_debug_conv_path(8)
         afdm.lib().afd_debug_conv_path(80)
+        afdm.lib().afd_debug_conv_path(60)
         afdm.lib().afd_debug_conv_path(74)
         afdm.lib().afd_debug_conv_path(84)
         afdm.lib().afd_debug_conv_path(92)
