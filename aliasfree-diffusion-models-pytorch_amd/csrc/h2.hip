@@ -113,12 +113,17 @@ __global__ __launch_bounds__(256, 2) void conv_h2(const float* __restrict__ x, c
   }
   const float* xb = x + (long)img0 * K * HW;
   float xr[NE][8];
+  // the chunk's loads.  32 x 32 maps: every lane issues every load (halo / padding tasks read element 0 and are zeroed in
+  // chunk_amax) -- the per-task exec masks cost a branch and a mask save / restore per pair of loads (27.6 -> 26.1, 47.3 -> 44.6 us
+  // on the 32-channel layers).  Smaller maps keep the masked form: a third of their tasks is padding and skipping those loads
+  // is worth more (8 x 8: 53.3 against 59.1 us at 256 -> 256).  Buffer loads (scalar descriptor + offset, one instruction per
+  // load) were measured too: no faster for x, 5-15 % slower for the weight fragments
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
       const float* p = xb + (long)k0 * HW + (s_src[e] >= 0 ? s_src[e] : 0);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xr[e][j] = s_src[e] >= 0 ? p[(long)j * HW] : 0.f;
+      for (int j = 0; j < 8; ++j) xr[e][j] = (S == 32 || s_src[e] >= 0) ? p[(long)j * HW] : 0.f;
     }
   };
   auto chunk_amax = [&]() {                                           // this wave's share of the staged chunk's max |x| -> wmax[wv]
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2(const float* __restrict__ x, c
 #pragma unroll
     for (int e = 0; e < NE; ++e)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(xr[e][j]));
+      for (int j = 0; j < 8; ++j) { xr[e][j] = s_src[e] >= 0 ? xr[e][j] : 0.f; m = fmaxf(m, fabsf(xr[e][j])); }
     m = wave_amax(m);
     if (lane == 0) wmax[wv] = m;
   };
@@ -354,11 +359,11 @@ __global__ __launch_bounds__(256, 2) void conv_h2l(const float* __restrict__ x, 
   }
   const float* xb = x + (long)img0 * K * HW;
   float xr[NE][8];
+  // EVERY lane issues EVERY load (halo / padding tasks read element 0 of the chunk and are zeroed at the chunk boundary): the
+  // counted wait at the end of filter row 1 relies on exactly NE * 8 loads being younger than that row's DMA pieces
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
-      // EVERY lane issues EVERY load (halo / padding tasks read element 0 of the chunk and are zeroed at the chunk boundary): the
-      // counted wait at the end of filter row 1 relies on exactly NE * 8 loads being younger than that row's DMA pieces
       const float* p = xb + (long)k0 * HW + (s_src[e] >= 0 ? s_src[e] : 0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) xr[e][j] = p[(long)j * HW];
