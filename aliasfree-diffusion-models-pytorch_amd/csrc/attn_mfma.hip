@@ -105,6 +105,15 @@ __device__ __forceinline__ f32x16 dotx3(const bf8 (&a)[3], const bf8 (&b)[3]) {
   return c;
 }
 
+// the same with the accumulator starting from c0 (a per-row constant folded into the product: S - lse, dP - delta)
+template <int D>
+__device__ __forceinline__ f32x16 dotx3c(const bf8 (&a)[3], const bf8 (&b)[3], f32x16 c) {
+  static_assert(D == 8, "dotx3c: head dim 8");
+#pragma unroll
+  for (int m = 0; m < 3; ++m) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[m], c, 0, 0, 0);
+  return c;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward: workgroup = 256 queries (4 waves x 2 query tiles of 32), streams K/V in tiles of 64 keys
 // ------------------------------------------------------------------------------------------------
@@ -210,7 +219,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const float* __restrict_
 // 8..15) x two (piece) MFMAs: one packed conversion per pair and piece
 using h2v = __attribute__((ext_vector_type(2))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
-__device__ __forceinline__ void pv_split16(const f32x16& sc, float off, h8 (&p1)[2], h8 (&p2)[2]) {
+// -1.0 in a scalar register the optimizer cannot see through: fma(piece, -1, x) with a literal -1 is folded back into a
+// conversion + subtraction; with an opaque factor it stays one v_fma_mix_f32 (the fp16 piece is read in place)
+__device__ __forceinline__ float opaque_neg1() {
+  float v;
+  asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(v));
+  return v;
+}
+__device__ __forceinline__ void pv_split16(const f32x16& sc, float off, float neg1, h8 (&p1)[2], h8 (&p2)[2]) {
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     u32x4 w1, w2;
@@ -218,7 +234,7 @@ __device__ __forceinline__ void pv_split16(const f32x16& sc, float off, h8 (&p1)
     for (int q = 0; q < 4; ++q) {
       const float x0 = __builtin_amdgcn_exp2f(sc[8 * g + 2 * q] - off), x1 = __builtin_amdgcn_exp2f(sc[8 * g + 2 * q + 1] - off);
       const h2v a = __builtin_convertvector((f2){x0, x1}, h2v);
-      const h2v c = __builtin_convertvector((f2){x0 - (float)a[0], x1 - (float)a[1]}, h2v);
+      const h2v c = __builtin_convertvector((f2){__builtin_fmaf((float)a[0], neg1, x0), __builtin_fmaf((float)a[1], neg1, x1)}, h2v);
       w1[q] = __builtin_bit_cast(uint32_t, a);
       w2[q] = __builtin_bit_cast(uint32_t, c);
     }
@@ -274,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pv(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   float sv = __uint_as_float(kH2ScaleCapBits);                        // running power-of-two scale of V
+  const float neg1 = opaque_neg1();
 
   const int jp0 = threadIdx.x >> 6, rr = threadIdx.x & 63;           // staging: d-pair (2 jp0, 2 jp0 + 1) of key row rr
   // where this thread's V elements go: key rr = 32 kt + rho, rho = (r & 3) + 8 (r >> 2) + 4 half' -> k-slot (half', j = r & 7) of MFMA g = r >> 3
@@ -335,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pv(const float* __restrict__ 
         for (int r = 0; r < 9; ++r) acc[j][r] *= alpha;                // eight sums + the row sum
         const float off = mn - 14.0f;                                  // P' = 2^14 P
         h8 p1[2], p2[2];
-        pv_split16(sc, off, p1, p2);
+        pv_split16(sc, off, neg1, p1, p2);
         __builtin_amdgcn_s_setprio(2);                                 // matrix-pipe phases issue ahead of the other wave's vector work
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av0, p1[0], acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av1, p1[1], acc[j], 0, 0, 0);
@@ -610,7 +627,7 @@ __global__ __launch_bounds__(256) void attn_delta_k(const float* __restrict__ o,
 }
 
 // two fp16 pieces of 16 fp32 values (the registers of one accumulator tile) as the operands of the two k-groups
-__device__ __forceinline__ void split16(const f32x16& v, h8 (&p1)[2], h8 (&p2)[2]) {
+__device__ __forceinline__ void split16(const f32x16& v, float neg1, h8 (&p1)[2], h8 (&p2)[2]) {
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     u32x4 w1, w2;
@@ -618,7 +635,7 @@ __device__ __forceinline__ void split16(const f32x16& v, h8 (&p1)[2], h8 (&p2)[2
     for (int q = 0; q < 4; ++q) {
       const float x0 = v[8 * g + 2 * q], x1 = v[8 * g + 2 * q + 1];
       const h2v a = __builtin_convertvector((f2){x0, x1}, h2v);
-      const h2v c = __builtin_convertvector((f2){__builtin_fmaf((float)a[0], -1.0f, x0), __builtin_fmaf((float)a[1], -1.0f, x1)}, h2v);   // (v_fma_mix_f32: the fp16 piece is read in place)
+      const h2v c = __builtin_convertvector((f2){__builtin_fmaf((float)a[0], neg1, x0), __builtin_fmaf((float)a[1], neg1, x1)}, h2v);   // (v_fma_mix_f32, opaque_neg1 above)
       w1[q] = __builtin_bit_cast(uint32_t, a);
       w2[q] = __builtin_bit_cast(uint32_t, c);
     }
@@ -650,9 +667,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused(const float* __restrict
   __shared__ __attribute__((aligned(16))) bf8 Bf[4][2][2][3][64];     // bf16x3 B fragments of the wave's key tiles: K (scaled), V
   __shared__ __attribute__((aligned(16))) float Ls[kTK];
   __shared__ __attribute__((aligned(16))) float Ds[kTK];
-  __shared__ __attribute__((aligned(16))) float Dw[4][kTK];            // delta x (this wave's dS scale 2^-14)
   __shared__ float DQ[4][D][kTK];                                      // the waves' dQ partials of one stage
-  __shared__ float wmax[3][4];
+  __shared__ float wmax[4][4];
   const int b = blockIdx.y, h = blockIdx.x, C = heads * D;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
   const float* qp = qkv + ((long)b * 3 * C + h * D) * L;
@@ -680,6 +696,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused(const float* __restrict
   const int sbase = ((((rr >> 5) * 2 + (sr >> 3)) * 2 + sh) * 16) * 8 + (sr & 7);         // + m * 8, m = d or d + 8
 
   float sq = __uint_as_float(kH2ScaleCapBits), sg = sq;                // running scales of Q and dO (workgroup)
+  const float neg1 = opaque_neg1();
   for (int kb = 0; kb < L; kb += 256) {
     const int key0 = kb + wv * 64;
     // ---- this wave's keys: bf16x3 B fragments (K scaled for the log2-domain scores, V), fp16 A operand of dQ (raw K), |V|_1
@@ -724,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused(const float* __restrict
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accV[j][r] = 0.f; accK[j][r] = 0.f; }
-    float sds = __uint_as_float(kH2ScaleCapBits);                      // this wave's running scale of dS
+    float sds = __uint_as_float(kH2ScaleCapBits);                      // the running scale of dS for this key block (workgroup-wide: it rides in the staged dO pieces)
 
     float qreg[2], greg[2], lreg = 0.f, dreg = 0.f;
     auto fetch = [&](int t0) {
@@ -751,26 +768,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused(const float* __restrict
         const float mq = wave_amax(fmaxf(fabsf(qreg[0]), fabsf(qreg[1])));
         const float mg = wave_amax(fmaxf(fabsf(greg[0]), fabsf(greg[1])));
         const float md = wave_amax(fabsf(dreg));                       // (threads >= 64 hold 0)
-        if (lane == 0) { wmax[0][wv] = mq; wmax[1][wv] = mg; wmax[2][wv] = md; }
+        if (lane == 0) { wmax[0][wv] = mq; wmax[1][wv] = mg; wmax[2][wv] = md; wmax[3][wv] = v1; }
       }
       __syncthreads();                                                 // A: the previous stage's reads are done, its dQ partials and the maxima visible
       const float mq = fmaxf(fmaxf(wmax[0][0], wmax[0][1]), fmaxf(wmax[0][2], wmax[0][3]));
       const float mg = fmaxf(fmaxf(wmax[1][0], wmax[1][1]), fmaxf(wmax[1][2], wmax[1][3]));
       const float md = fmaxf(fmaxf(wmax[2][0], wmax[2][1]), fmaxf(wmax[2][2], wmax[2][3]));
+      const float v1g = fmaxf(fmaxf(wmax[3][0], wmax[3][1]), fmaxf(wmax[3][2], wmax[3][3]));   // max_key |V|_1 over the block's 256 keys
       {
         const float sqn = fminf(sq, h2_scale_for(mq)), sgn = fminf(sg, h2_scale_for(mg));
-        const float sdn = fminf(sds, h2_scale_for(fmaf(v1, mg, md)));  // |dS| <= |V|_1 max|dO| + max|delta|
-        const float fk = (sqn * h2_inv_pow2(sq)) * (sdn * h2_inv_pow2(sds)), fv = sgn * h2_inv_pow2(sg);
+        const float sdn = fminf(sds, h2_scale_for(fmaf(v1g, mg, md))); // |dS| <= |V|_1 max|dO| + max|delta|
+        // (and c max|dO| stays finite where V and delta vanish: blocks whose dS is below 2^-49 max|dO| are not resolved further)
+        const float sdc = fminf(sdn, h2_scale_for(mg) * 0x1p64f);
+        const float fk = (sqn * h2_inv_pow2(sq)) * (sdc * h2_inv_pow2(sds)), fv = sgn * h2_inv_pow2(sg);
         if (fk != 1.0f || fv != 1.0f) {                                // (uniform per wave)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 8; ++r) { accK[j][r] *= fk; accV[j][r] *= fv; }
         }
-        sq = sqn; sg = sgn; sds = sdn;
+        sq = sqn; sg = sgn; sds = sdc;
       }
+      // dS' = P' (dP - delta) c, c = s_ds 2^-14 (P' = 2^14 P): the factor c rides in the staged dO pieces (a power of two: exact)
+      // and both per-query constants start the accumulators of their products -- S - (lse log2(e) - 14) and c dP - c delta leave
+      // the matrix pipe ready, one exp2 and one multiply per pair remain on the vector pipe
+      const float cds = sds * (1.0f / 16384.0f);
       stage_pieces<D>(Qp, rr, jp0, qreg[0], qreg[1]);
-      stage_pieces<D>(Gp, rr, jp0, greg[0], greg[1]);
+      stage_pieces<D>(Gp, rr, jp0, greg[0] * cds, greg[1] * cds);
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         _Float16 a, c;
@@ -779,14 +803,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused(const float* __restrict
         h2_split(greg[hh], sg, a, c);
         GA[sbase + (2 * jp0 + hh) * 8] = a; GA[sbase + (2 * jp0 + hh + 8) * 8] = c;
       }
-      // dS' = P' (dP - delta) s_ds 2^-14 = P' fma(dP, c, -delta c): the rows carry lse log2(e) - 14 (P' = 2^14 P) and delta c.
-      // Every wave has ITS OWN c (its dS scale follows its keys' |V|_1), so the delta rows are kept per wave.
-      const float cds = sds * (1.0f / 16384.0f);
-      if (threadIdx.x < kTK) Ls[threadIdx.x] = lreg - 14.0f;
+      if (threadIdx.x < kTK) Ls[threadIdx.x] = 14.0f - lreg;           // (negated: the rows are accumulator start values)
       if (t0 > 0) dq_flush(t0 - kTK);
-      if (threadIdx.x < kTK) Ds[threadIdx.x] = dreg;
+      if (threadIdx.x < kTK) Ds[threadIdx.x] = -dreg * cds;
       __syncthreads();                                                 // B
-      Dw[wv][lane] = Ds[lane] * cds;                                   // (wave-private: in-order LDS, no barrier)
       if (t0 + kTK < L) fetch(t0 + kTK);
       const float udq = (scale * h2_inv_pow2(sds)) * h2_inv_pow2(sk);  // dQ partials leave unscaled
 #pragma unroll
@@ -801,37 +821,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused(const float* __restrict
         for (int j = 0; j < 2; ++j) {
           // (operands are fetched from LDS right where they are used: the accumulators of five products leave few registers)
           f32x16 sc, dp;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {                             // registers 4 r4 .. 4 r4 + 3 are four consecutive query rows
+            const int qr = qt * 32 + 8 * r4 + 4 * half;
+            const float4 ls = *reinterpret_cast<const float4*>(Ls + qr), dl = *reinterpret_cast<const float4*>(Ds + qr);
+            sc[4 * r4] = ls.x; sc[4 * r4 + 1] = ls.y; sc[4 * r4 + 2] = ls.z; sc[4 * r4 + 3] = ls.w;
+            dp[4 * r4] = dl.x; dp[4 * r4 + 1] = dl.y; dp[4 * r4 + 2] = dl.z; dp[4 * r4 + 3] = dl.w;
+          }
           {
             bf8 aq[3], bkj[3];
             load_frags<D>(Qp, qt * 32 + l31, half, aq);
 #pragma unroll
             for (int m = 0; m < 3; ++m) bkj[m] = Bf[wv][j][0][m][lane];
-            sc = dotx3<D>(aq, bkj);
+            sc = dotx3c<D>(aq, bkj, sc);
           }
           {
             bf8 ag[3], bvj[3];
             load_frags<D>(Gp, qt * 32 + l31, half, ag);
 #pragma unroll
             for (int m = 0; m < 3; ++m) bvj[m] = Bf[wv][j][1][m][lane];
-            dp = dotx3<D>(ag, bvj);
+            dp = dotx3c<D>(ag, bvj, dp);
           }
 #pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {                             // registers 4 r4 .. 4 r4 + 3 are four consecutive query rows
-            const int qr = qt * 32 + 8 * r4 + 4 * half;
-            const float4 ls = *reinterpret_cast<const float4*>(Ls + qr), dl = *reinterpret_cast<const float4*>(&Dw[wv][qr]);
-            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int r = 4 * r4 + i;
-              const float pv = __builtin_amdgcn_exp2f(sc[r] - lsv[i]);                    // P' = 2^14 P
-              sc[r] = pv;
-              dp[r] = pv * __builtin_fmaf(dp[r], cds, -dlv[i]);                           // dS'
-            }
+          for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(sc[r]);                               // P' = 2^14 P
+            sc[r] = pv;
+            dp[r] *= pv;                                                                  // dS'
           }
           __builtin_amdgcn_sched_barrier(0);
           h8 p1[2], p2[2];
           {
-            split16(sc, p1, p2);
+            split16(sc, neg1, p1, p2);
             const h8 ga0 = ga[a_rec(qt, 0)], ga1 = ga[a_rec(qt, 1)];
             __builtin_amdgcn_s_setprio(2);                             // matrix-pipe phases issue ahead of the other wave's vector work
             accV[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga0, p1[0], accV[j], 0, 0, 0);
@@ -842,7 +862,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused(const float* __restrict
           __builtin_amdgcn_s_setprio(0);
           __builtin_amdgcn_sched_barrier(0);
           {
-            split16(dp, p1, p2);
+            split16(dp, neg1, p1, p2);
             const h8 qa0 = qa[a_rec(qt, 0)], qa1 = qa[a_rec(qt, 1)];
             __builtin_amdgcn_s_setprio(2);
             accK[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa0, p1[0], accK[j], 0, 0, 0);
