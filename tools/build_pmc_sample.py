@@ -25,7 +25,7 @@ def load(d):
 
 
 pers = [load(os.path.join(root, k)) for k in ("fetch", "write", "sq1")]
-groups = {"conv3x3_fwd": {"conv_h2", "conv_h2_sk", "conv_wino", "conv_wino_sk", "conv_mfma", "conv_bf3"},
+groups = {"conv3x3_fwd": {"conv_h2", "conv_h2l", "conv_h2_sk", "conv_wino", "conv_wino_sk", "conv_mfma", "conv_bf3"},
           "attn_fwd": {"attn_fwd_pv", "attn_fwd_mfma", "attn_fwd_k"},
           "filt_act_fwd_n3": {"filt_act_fwd_n3"}, "groupnorm1_fwd_full": {"gn_fwd_reg", "gn_fwd_loop"},
           "tok_head_fwd": {"tok_head_fwd", "tok_head_fwd_wide"}, "tok_tail_fwd": {"tok_tail_fwd", "tok_tail_fwd_wide"}}
