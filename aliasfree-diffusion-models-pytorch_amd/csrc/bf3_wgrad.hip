@@ -614,8 +614,12 @@ int pw_wgrad_bf3_plan(int B, int Cin, int Cout, int L, int* sps, int* nsteps, in
   while (roles % NR) NR >>= 1;                                         // roles per workgroup: a power of two dividing the role count
   const long st = (long)B * L / 32;
   const long gy = roles / NR;
-  static const long target = [] { const char* e = getenv("AFD_PWB_TARGET"); return e ? atol(e) : 256L; }();   // tuning hook
+  const char* e = getenv("AFD_PWB_TARGET");                            // tuning hooks, read per call (tools/ab_env.py)
+  const long target = e ? atol(e) : 256L;
+  const char* e2 = getenv("AFD_PWB_MINSTEPS");
+  const long minsteps = (e2 ? atol(e2) : 1L) * (8 / NR);               // steps per split: at least this many per pixel slice of a workgroup
   long s = target / gy;
+  if (s > st / minsteps) s = st / minsteps;
   if (s < 1) s = 1;
   if (s > st) s = st;
   const long c = (st + s - 1) / s;

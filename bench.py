@@ -14,6 +14,7 @@ on the launch stream), `kernels` (every kernel family timed the same way), `cpu_
 (the CPU oracle's train step on the host cores, bounded sample), `sample` (Diffusion.sample).
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -485,8 +486,8 @@ def cpu_baseline(variant=3, batch=256):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--variant", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true", help="eager launches only")
@@ -543,7 +544,8 @@ def main():
                 st(images)
             return st, False
 
-    def probe(st, n=6):
+    def probe(st, n=12):
+        gc.collect()
         sync()
         t0 = time.perf_counter()
         for _ in range(n):
@@ -570,6 +572,11 @@ def main():
         if t_eager < t_graph:
             del step
             step, graph_ok = make_step(False)
+    # Python's cyclic collector is run before and switched off during the timed steps (timeit's convention): a full collection
+    # walks every module / tensor object of the process (~30 ms: one 20-step window in forty read 8.6 instead of 7.04 ms/step,
+    # tools/jitter_probe.py); the steps themselves create no reference cycles that need it
+    gc.collect()
+    gc.disable()
     sync()
     log("timing train steps")
     t0 = time.perf_counter()
@@ -577,6 +584,7 @@ def main():
         loss = step(images)
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -591,7 +599,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"CIFAR-10 32x32x3 synthetic, UNet variant={args.variant} (Config {'ABCDE'[args.variant]}), "
                                f"batch {args.batch}/GPU, T=1000, AdamW lr 3e-4, random-init weights (seed 42)",
-                   "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": graph_ok},
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": graph_ok,
+                   "host_gc": "collected before, disabled during the timed steps (timeit's convention)"},
         "final_loss": round(final_loss, 5),
     }
 

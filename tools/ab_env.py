@@ -1,6 +1,6 @@
 """Same-box, same-process A/B of the B=256 train step over values of an environment variable that the step reads on every
 call (AFD_FOLD_EVERY, ...), interleaved.   python tools/ab_env.py VAR v1 v2 [v3 ...] [--batch 256] [--rounds 4]"""
-import sys, os, math, time
+import sys, os, math, time, gc
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, afdm
 args = sys.argv[1:]
@@ -20,6 +20,7 @@ st = afdm.TrainStep(model, diff, lr=3e-4, graph=False)
 for _ in range(10):
     st(images)
 res = {v: [] for v in vals}
+gc.collect(); gc.disable()          # (a full collection costs ~30 ms: one window in forty; tools/jitter_probe.py)
 for rnd in range(R):
     for v in vals:
         os.environ[var] = v
@@ -31,4 +32,4 @@ for rnd in range(R):
         torch.cuda.synchronize()
         res[v].append((time.perf_counter() - t0) / 40 * 1e3)
 for v in vals:
-    print(f"{var}={v}: " + " ".join(f"{r:.3f}" for r in res[v]) + f"  best {min(res[v]):.3f} ms/step", flush=True)
+    print(f"{var}={v}: " + " ".join(f"{r:.3f}" for r in res[v]) + f"  best {min(res[v]):.3f} median {sorted(res[v])[len(res[v]) // 2]:.3f} ms/step", flush=True)
