@@ -278,20 +278,29 @@ class TrainStep:
         # the CUs the dependent chain of small kernels leaves idle.  Measured on MI355X (B=256): eager 12.0 -> 11.1
         # ms/step, captured graph 11.45 -> 11.3 (forks batched 16 layers at a time: every fork is a cross-stream edge
         # in the graph, and 57 of them cost more than the overlap returns).  Layers per fork, eager: 1 / 2 / 4 / 8 / 16 ->
-        # 9.77 / 9.67 / 9.66 / 9.87 / 9.95 ms.  Stream priorities (side high, or main high) both measured slower.
+        # 9.77 / 9.67 / 9.66 / 9.87 / 9.95 ms.  (Stream priorities: see _main_hi below.)
         if overlap_wgrad is None:
             overlap_wgrad = True
         n_side = int(os.environ.get("AFD_WGRAD_STREAMS", 1))                                # side streams (tuning hook)
-        self.wgrad_stream = [torch.cuda.Stream() for _ in range(max(1, n_side))] if overlap_wgrad else None
+        prio = int(os.environ.get("AFD_WGRAD_PRIO", 0))                                   # side-stream priority (tuning hook; larger = lower)
+        self.wgrad_stream = [torch.cuda.Stream(priority=prio) for _ in range(max(1, n_side))] if overlap_wgrad else None
         # layers per fork (AFD_WGRAD_BATCH overrides, read per step: tuning hook).  Round 3, after the convolutions moved to the
         # fp16 matrix pipe (tools/ab_env.py AFD_WGRAD_BATCH, same box): 2 / 4 / 8 / 12 / 16 -> 7.49 / 7.46 / 7.32 / 7.34 / 7.34 ms
-        self.wgrad_batch = 16 if graph else 8
+        # Re-measured with medians over windows (tools/step_median.py, separate processes): eager 4 / 6 / 8 / 10 / 12 / 16 -> 7.264 / 7.109 /
+        # 7.097 / 7.133 / 7.147 / 7.182; captured 8 / 16 / 24 / 32 / 40 / 48 / 64 / 128 -> 7.343 / 7.285 / 7.220 / 7.208 / 7.299 / 7.375 / 7.361 / 7.552
+        self.wgrad_batch = 32 if graph else 8
         self.opt = FusedAdamW(model, lr=lr, conditional=conditional)
         want_ddp = distributed if distributed is not None else dist.is_initialized()
         self.ddp = GradAllReduce(self.opt.fp, n_buckets, model=model) if want_ddp else None
         if self.ddp is not None:
             self.ddp.side = self.wgrad_stream
         self._loss_work = None
+        # The dependent chain (forward, dgrads, norms, attention, AdamW) runs on a HIGH-priority stream, the weight gradients on a
+        # normal one: the dispatcher then hands free CUs to the chain first and the weight-gradient workgroups (512 threads, a
+        # CU's whole register file) fill what is left, instead of the two competing as equals.  Same box, interleaved windows
+        # (tools/ab_prio.py): 7.335 -> 7.040 ms/step; the weight-gradient stream at high priority instead: 14.0.  (Round 1
+        # measured priorities as a loss; the kernels were 1.6x slower and bound elsewhere then.)  AFD_MAIN_PRIO=0 turns it off.
+        self._main_hi = torch.cuda.Stream(priority=-1) if int(os.environ.get("AFD_MAIN_PRIO", 0)) and torch.cuda.is_available() else None
         self.use_graph = graph
         self._graph = None
         self._static = None
@@ -315,7 +324,13 @@ class TrainStep:
             with ops.inplace_param_grads(self.wgrad_stream, int(os.environ.get("AFD_WGRAD_BATCH", self.wgrad_batch)),   # weight gradients add straight into the flat .grad views
                                          on_write=self.ddp.wrote if overlap else None,
                                          fold_hint=self.ddp.would_complete if overlap else None):
-                loss.backward()
+                # backward on the calling thread instead of the autograd engine's device worker thread: no hand-over of the
+                # interpreter lock per node (host time of a step 6.34 -> 5.6 ms, tools/step_median.py at B = 8; AFD_BWD_THREAD=1: the engine's thread)
+                if os.environ.get("AFD_BWD_THREAD", "0") == "1":
+                    loss.backward()
+                else:
+                    with torch.autograd.set_multithreading_enabled(False):
+                        loss.backward()
                 if overlap:
                     self.ddp.backward_done()
         finally:
@@ -347,6 +362,13 @@ class TrainStep:
             t = self.diffusion.sample_timesteps(images.shape[0])
         t = t.to(images.device, non_blocking=True)
         if not self.use_graph:
+            if self._main_hi is not None:             # the dependent chain on the high-priority stream, joined with the caller's on both sides
+                cur = torch.cuda.current_stream()
+                self._main_hi.wait_stream(cur)
+                with torch.cuda.stream(self._main_hi):
+                    loss = self._body(images, t, eps, y)
+                cur.wait_stream(self._main_hi)
+                return loss
             return self._body(images, t, eps, y)
         whole = self.ddp is None                    # single GPU: AdamW is captured too
         if self._graph is None:
@@ -370,7 +392,7 @@ class TrainStep:
             torch.cuda.set_rng_state(rng, images.device)
             ops.bump_param_epoch()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with (torch.cuda.graph(self._graph, stream=self._main_hi) if self._main_hi is not None else torch.cuda.graph(self._graph)):   # (captured on the high-priority stream: the kernel nodes keep it)
                 st["loss"] = (self._body if whole else self._fwd_bwd)(st["images"], st["t"], st["eps"])
         st = self._static
         if (eps is None) != (st["eps"] is None):
