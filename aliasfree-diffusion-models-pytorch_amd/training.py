@@ -266,7 +266,12 @@ class TrainStep:
     `graph=True` captures the device work into a hipGraph on first use (static shapes): the whole step on
     one GPU; with data parallelism everything up to and including backward -- the gradient all-reduce
     (one 23.6 MB exchange) and AdamW then run after the replay.  The CPU-generator timestep draw and the
-    H2D copies always stay outside the graph."""
+    H2D copies always stay outside the graph.
+    `graph="lanes"` captures the same graph but never launches it: csrc/replay.hip walks its nodes once and re-issues
+    them on TWO REAL STREAMS from a C++ loop (weight-gradient kernels on the side stream, cross-lane dependencies as
+    events) -- the eager step's stream semantics with ~0.7 instead of 5.6 ms of host time per step and none of a
+    hipGraph launch's cross-branch cost: 6.79 / 6.84 / 7.00 ms (lanes / eager / hipGraph) at B = 256, 3.7 / 5.2 / 4.0 at
+    B = 16, bit-identical to the eager step.  The noise is drawn outside the replayed list (no generator state in it)."""
 
     def __init__(self, model, diffusion, lr, graph=False, distributed=None, n_buckets=4, overlap_wgrad=None, conditional=False):
         """conditional=True: the step takes class labels (`step(images, y=labels)`, UNet.forward(x, t, y): ddpm_models.py:276-277)
@@ -288,7 +293,7 @@ class TrainStep:
         # fp16 matrix pipe (tools/ab_env.py AFD_WGRAD_BATCH, same box): 2 / 4 / 8 / 12 / 16 -> 7.49 / 7.46 / 7.32 / 7.34 / 7.34 ms
         # Re-measured with medians over windows (tools/step_median.py, separate processes): eager 4 / 6 / 8 / 10 / 12 / 16 -> 7.264 / 7.109 /
         # 7.097 / 7.133 / 7.147 / 7.182; captured 8 / 16 / 24 / 32 / 40 / 48 / 64 / 128 -> 7.343 / 7.285 / 7.220 / 7.208 / 7.299 / 7.375 / 7.361 / 7.552
-        self.wgrad_batch = 32 if graph else 8
+        self.wgrad_batch = 8 if (not graph or graph == "lanes") else 32      # ("lanes" has the eager step's stream semantics)
         self.opt = FusedAdamW(model, lr=lr, conditional=conditional)
         want_ddp = distributed if distributed is not None else dist.is_initialized()
         self.ddp = GradAllReduce(self.opt.fp, n_buckets, model=model) if want_ddp else None
@@ -301,7 +306,9 @@ class TrainStep:
         # (tools/ab_prio.py): 7.335 -> 7.040 ms/step; the weight-gradient stream at high priority instead: 14.0.  (Round 1
         # measured priorities as a loss; the kernels were 1.6x slower and bound elsewhere then.)  AFD_MAIN_PRIO=0 turns it off.
         self._main_hi = torch.cuda.Stream(priority=-1) if int(os.environ.get("AFD_MAIN_PRIO", 0)) and torch.cuda.is_available() else None
-        self.use_graph = graph
+        self.use_graph = bool(graph)
+        self.lanes = graph == "lanes"     # the captured step re-issued on two real streams from C++ (csrc/replay.hip)
+        self._lanes_handle = None
         self._graph = None
         self._static = None
         self._wino_plan, self._wino_requests = None, None      # ops.WinoStepPlan after the first (recording) step
@@ -361,6 +368,8 @@ class TrainStep:
         if t is None:
             t = self.diffusion.sample_timesteps(images.shape[0])
         t = t.to(images.device, non_blocking=True)
+        if self.lanes and eps is None:
+            eps = torch.randn_like(images)          # drawn outside: the replayed list holds no generator state
         if not self.use_graph:
             if self._main_hi is not None:             # the dependent chain on the high-priority stream, joined with the caller's on both sides
                 cur = torch.cuda.current_stream()
@@ -391,9 +400,14 @@ class TrainStep:
                 b.copy_(k)
             torch.cuda.set_rng_state(rng, images.device)
             ops.bump_param_epoch()
-            self._graph = torch.cuda.CUDAGraph()
+            self._graph = torch.cuda.CUDAGraph(keep_graph=True) if self.lanes else torch.cuda.CUDAGraph()
             with (torch.cuda.graph(self._graph, stream=self._main_hi) if self._main_hi is not None else torch.cuda.graph(self._graph)):   # (captured on the high-priority stream: the kernel nodes keep it)
                 st["loss"] = (self._body if whole else self._fwd_bwd)(st["images"], st["t"], st["eps"])
+            if self.lanes:
+                import ctypes
+                h, counts = ctypes.c_void_p(), (ctypes.c_int * 4)()
+                lib().afd_replay_build(self._graph.raw_cuda_graph(), ctypes.byref(h), counts)
+                self._lanes_handle, self.lanes_counts = h, tuple(counts)      # (work nodes, main lane, side lane, cross-lane waits)
         st = self._static
         if (eps is None) != (st["eps"] is None):
             raise ValueError("TrainStep(graph=True): the step was captured " + ("without" if st["eps"] is None else "with") +
@@ -402,7 +416,10 @@ class TrainStep:
         st["t"].copy_(t)
         if eps is not None:
             st["eps"].copy_(eps)
-        self._graph.replay()
+        if self.lanes:
+            lib().afd_replay_run(self._lanes_handle, torch.cuda.current_stream().cuda_stream, self.wgrad_stream[0].cuda_stream)
+        else:
+            self._graph.replay()
         ops.bump_param_epoch()                          # the replayed AdamW moved the parameters
         if not whole:
             self.ddp.begin_step()                       # the replayed backward reported nothing: exchange everything now

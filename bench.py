@@ -556,22 +556,26 @@ def main():
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)        # every rank takes the same decision
         return dt.item() / n
 
-    # launch mode: the same step either replayed from a captured hipGraph or launched eagerly (with the weight-gradient
-    # kernels overlapped on a second stream in both).  Which is faster depends on how quickly the host issues ~1000
-    # launches per step, so by default both are probed after warm-up (untimed) and the faster one is measured.
+    # launch mode: the same step launched eagerly (with the weight-gradient kernels overlapped on a second stream), replayed from a
+    # captured hipGraph, or re-issued from the captured graph on two real streams by a C++ loop ("lanes": csrc/replay.hip -- the
+    # eager step's stream semantics without the interpreter).  Which is fastest depends on how quickly the host issues ~330
+    # launches per step (5.6 ms of interpreter time against 6.7-7.0 ms of device time), so by default all three are probed
+    # after warm-up (untimed) and the fastest one is measured.
     if args.no_graph or args.graph:
         step, graph_ok = make_step(args.graph)
-        log(f"rank {rank}/{world}: model ready ({'hipGraph' if graph_ok else 'eager'})")
+        mode = "hipGraph" if graph_ok else "eager"
+        log(f"rank {rank}/{world}: model ready ({mode})")
     else:
-        step, graph_ok = make_step(False)
-        t_eager = probe(step)
-        del step
-        step, graph_ok = make_step(True)
-        t_graph = probe(step) if graph_ok else float("inf")
-        log(f"rank {rank}/{world}: probe eager {t_eager * 1e3:.2f} ms/step, hipGraph {t_graph * 1e3:.2f} ms/step")
-        if t_eager < t_graph:
+        probes = {}
+        for mode, g in (("eager", False), ("hipGraph", True), ("lanes", "lanes")):
+            step, ok = make_step(g)
+            probes[mode] = probe(step) if (ok or not g) else float("inf")
             del step
-            step, graph_ok = make_step(False)
+        log(f"rank {rank}/{world}: probe " + ", ".join(f"{k} {v * 1e3:.2f} ms/step" for k, v in probes.items()))
+        mode = min(probes, key=probes.get)
+        step, graph_ok = make_step({"eager": False, "hipGraph": True, "lanes": "lanes"}[mode])
+        if not graph_ok:
+            mode = "eager"
     # Python's cyclic collector is run before and switched off during the timed steps (timeit's convention): a full collection
     # walks every module / tensor object of the process (~30 ms: one 20-step window in forty read 8.6 instead of 7.04 ms/step,
     # tools/jitter_probe.py); the steps themselves create no reference cycles that need it
@@ -599,7 +603,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"CIFAR-10 32x32x3 synthetic, UNet variant={args.variant} (Config {'ABCDE'[args.variant]}), "
                                f"batch {args.batch}/GPU, T=1000, AdamW lr 3e-4, random-init weights (seed 42)",
-                   "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": graph_ok,
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": bool(graph_ok), "launch_mode": mode,
                    "host_gc": "collected before, disabled during the timed steps (timeit's convention)"},
         "final_loss": round(final_loss, 5),
     }

@@ -377,6 +377,19 @@ int afd_adamw_step(float* p, const float* g, float* m, float* v, long n, const f
                    float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                    afd_stream_t stream);
 
+/* ---- two-lane replay of a captured step (csrc/replay.hip) --------------------------------- training.TrainStep(graph="lanes")
+ * A step captured by the host framework as a hipGraph (forward, backward with the weight gradients forked to a side stream,
+ * AdamW) is re-issued from a C++ loop on TWO REAL STREAMS: afd_replay_build walks the graph once (kernel / memset / flat
+ * memcpy nodes; no-op and event nodes are folded into the dependencies), puts the weight-gradient kernels (by name) on the side
+ * lane and everything else on the main lane, and turns the dependencies that cross lanes into event record / wait pairs;
+ * afd_replay_run launches the nodes in capture order, each on its lane's stream.  The graph -- and the memory its nodes
+ * point into -- must outlive the handle.  counts (may be NULL) receives {work nodes, main lane, side lane, cross-lane waits}.
+ * Replaces nothing in the reference (its loop is eager PyTorch, ddpm_utils.py:494-509): it removes the interpreter from the
+ * steady-state step without the cross-branch cost of a hipGraph launch. */
+int afd_replay_build(void* hip_graph, void** out_handle, int* counts);
+int afd_replay_run(void* handle, afd_stream_t main_stream, afd_stream_t side_stream);
+int afd_replay_free(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

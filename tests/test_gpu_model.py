@@ -337,18 +337,27 @@ def test_graph_replay_equals_eager(A):
     images, t0, e0 = T(g["images"]).to(dev), T(g["t0"]), T(g["eps0"]).to(dev)
     t1, e1 = T(g["t1"]), T(g["eps1"]).to(dev)
     outs = []
-    for use_graph in (False, True):
+    for use_graph in (False, True, "lanes"):                              # "lanes": the captured step re-issued on two real streams (csrc/replay.hip)
         model, diff = _train_setup(afdm, dev)
         step = afdm.TrainStep(model, diff, lr=3e-4, graph=use_graph)      # the capture warm-up must leave no trace: the
         la = step(images, t=t0, eps=e0).item()                            # first graph call is exactly one step
         lb = step(images, t=t1, eps=e1).item()
         outs.append((la, lb, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()))
-    print("graph vs eager after 2 steps: loss diffs", abs(outs[0][0] - outs[1][0]), abs(outs[0][1] - outs[1][1]),
-          "param rel-L2", rel_l2(outs[1][2], outs[0][2]))
-    assert abs(outs[0][0] - outs[1][0]) < 1e-6 and abs(outs[0][1] - outs[1][1]) < 1e-5
-    assert rel_l2(outs[1][2], outs[0][2]) < 1e-6
+        if use_graph is True:
+            graph_step = step
+        if use_graph == "lanes":
+            n, n_main, n_side, n_wait = step.lanes_counts
+            print("two-lane replay:", step.lanes_counts)
+            assert n == n_main + n_side and n_side >= 40 and 2 <= n_wait <= n_side      # the weight gradients sit on the side lane, joined by a few events
+    for k, tag in ((1, "graph"), (2, "lanes")):
+        print(tag, "vs eager after 2 steps: loss diffs", abs(outs[0][0] - outs[k][0]), abs(outs[0][1] - outs[k][1]),
+              "param rel-L2", rel_l2(outs[k][2], outs[0][2]))
+        assert abs(outs[0][0] - outs[k][0]) < 1e-6 and abs(outs[0][1] - outs[k][1]) < 1e-5
+        assert rel_l2(outs[k][2], outs[0][2]) < 1e-6
+    assert torch.equal(outs[2][2], outs[1][2])                            # the same captured launches, issued differently: bit-identical
     with pytest.raises(ValueError, match="injected noise"):
-        step(images, t=t0)                                                # captured with eps: omitting it later is an error
+        graph_step(images, t=t0)                                          # captured with eps: omitting it later is an error
+    assert torch.isfinite(step(images, t=t0)).item()                      # ("lanes" draws the noise outside the replayed list: either way)
 
 
 def test_unused_parameters_stay_untouched_like_the_reference(A):

@@ -1,10 +1,10 @@
 """Median over windows of the B=256 train step of ONE TrainStep in this process (configured by environment variables; run the
-variants as separate processes, alternating).   python tools/step_median.py [--graph] [--windows 30]"""
+variants as separate processes, alternating).   python tools/step_median.py [--graph | --lanes] [--windows 30]"""
 import sys, os, math, time, gc
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, afdm
 dev = torch.device("cuda:0"); B = int(os.environ.get("AFD_B", 256))
-graph = "--graph" in sys.argv
+graph = "lanes" if "--lanes" in sys.argv else "--graph" in sys.argv
 W = int(sys.argv[sys.argv.index("--windows") + 1]) if "--windows" in sys.argv else 30
 F_SET = {"kernel_size": 3, "kaiser_beta": 2, "omega_c_down": math.pi / 2, "omega_c_up": math.pi / 2}
 afdm.set_seed(42)
@@ -22,5 +22,7 @@ for _ in range(W):
         loss = st(images)
     torch.cuda.synchronize()
     w.append((time.perf_counter() - t0) / 20 * 1e3)
-s = sorted(w)
-print(f"{'graph' if graph else 'eager'} {os.environ.get('TAG', '')}: median {s[len(s)//2]:.3f} min {s[0]:.3f} p90 {s[int(len(s)*0.9)]:.3f} loss {float(loss):.4f}", flush=True)
+s_ = sorted(w)
+mode = "lanes" if graph == "lanes" else "graph" if graph else "eager"
+extra = f" {st.lanes_counts}" if graph == "lanes" else ""
+print(f"{mode} {os.environ.get('TAG', '')}{extra}: median {s_[len(s_)//2]:.3f} min {s_[0]:.3f} p90 {s_[int(len(s_)*0.9)]:.3f} loss {float(loss):.4f}", flush=True)
