@@ -300,11 +300,11 @@ class TrainStep:
         if self.ddp is not None:
             self.ddp.side = self.wgrad_stream
         self._loss_work = None
-        # The dependent chain (forward, dgrads, norms, attention, AdamW) runs on a HIGH-priority stream, the weight gradients on a
-        # normal one: the dispatcher then hands free CUs to the chain first and the weight-gradient workgroups (512 threads, a
-        # CU's whole register file) fill what is left, instead of the two competing as equals.  Same box, interleaved windows
-        # (tools/ab_prio.py): 7.335 -> 7.040 ms/step; the weight-gradient stream at high priority instead: 14.0.  (Round 1
-        # measured priorities as a loss; the kernels were 1.6x slower and bound elsewhere then.)  AFD_MAIN_PRIO=0 turns it off.
+        # Tuning hook: the dependent chain (forward, dgrads, norms, attention, AdamW) on a HIGH-priority stream, the weight gradients on a
+        # normal one -- the idea being that the dispatcher hands free CUs to the chain first.  It does not pay.
+        # Measured in separate processes (tools/step_median.py): 7.22 against 7.16 eager, 12.3 against 7.13 with the two-lane replay, 13.3 with a
+        # graph captured on it; the weight-gradient stream at high priority instead: 14.0 -- mixed priorities make every cross-stream
+        # wait expensive.  Off by default (AFD_MAIN_PRIO=1 turns it on for eager launches).
         self._main_hi = torch.cuda.Stream(priority=-1) if int(os.environ.get("AFD_MAIN_PRIO", 0)) and torch.cuda.is_available() else None
         self.use_graph = bool(graph)
         self.lanes = graph == "lanes"     # the captured step re-issued on two real streams from C++ (csrc/replay.hip)
@@ -401,7 +401,7 @@ class TrainStep:
             torch.cuda.set_rng_state(rng, images.device)
             ops.bump_param_epoch()
             self._graph = torch.cuda.CUDAGraph(keep_graph=True) if self.lanes else torch.cuda.CUDAGraph()
-            with (torch.cuda.graph(self._graph, stream=self._main_hi) if self._main_hi is not None else torch.cuda.graph(self._graph)):   # (captured on the high-priority stream: the kernel nodes keep it)
+            with torch.cuda.graph(self._graph):
                 st["loss"] = (self._body if whole else self._fwd_bwd)(st["images"], st["t"], st["eps"])
             if self.lanes:
                 import ctypes
