@@ -28,6 +28,7 @@ struct ReplayNode {
 struct ReplayPlan {
   std::vector<ReplayNode> nodes;       // work nodes in capture (= a topological) order
   int n_main = 0, n_side = 0, n_edges = 0;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the side lane starts behind the main stream's current tail and the main stream ends behind the side lane's
 };
 
 static bool side_kernel(const char* name) {
@@ -141,6 +142,10 @@ int afd_replay_build(void* hip_graph, void** out_handle, int* counts) {
     }
     (r.lane ? plan->n_side : plan->n_main)++;
   }
+  if (hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) != hipSuccess) {
+    delete plan;
+    return set_error(AFD_ELAUNCH, "afd_replay_build: hipEventCreate failed");
+  }
   *out_handle = plan;
   if (counts) { counts[0] = (int)plan->nodes.size(); counts[1] = plan->n_main; counts[2] = plan->n_side; counts[3] = plan->n_edges; }
   return AFD_OK;
@@ -150,8 +155,11 @@ int afd_replay_run(void* handle, afd_stream_t main_stream, afd_stream_t side_str
   AFD_REQUIRE(handle, "afd_replay_run: null handle");
   auto plan = static_cast<ReplayPlan*>(handle);
   hipStream_t st[2] = {as_stream(main_stream), as_stream(side_stream)};
-  // the side lane starts behind whatever the main stream holds already (the inputs' copies), and the main stream ends behind it
-  hipEvent_t fork = nullptr;
+  // the side lane starts behind whatever the main stream holds already (the inputs' copies) ...
+  if (plan->n_side) {
+    if (hipEventRecord(plan->ev_fork, st[0]) != hipSuccess || hipStreamWaitEvent(st[1], plan->ev_fork, 0) != hipSuccess)
+      return set_error(AFD_ELAUNCH, "afd_replay_run: fork failed");
+  }
   for (auto& r : plan->nodes) {
     hipStream_t s = st[r.lane];
     for (int d : r.wait)
@@ -172,7 +180,12 @@ int afd_replay_run(void* handle, afd_stream_t main_stream, afd_stream_t side_str
     if (e != hipSuccess) return set_error(AFD_ELAUNCH, "afd_replay_run: node launch failed: %s", hipGetErrorString(e));
     if (r.ev && hipEventRecord(r.ev, s) != hipSuccess) return set_error(AFD_ELAUNCH, "afd_replay_run: hipEventRecord failed");
   }
-  (void)fork;
+  // ... and the main stream ends behind the side lane's tail: a graph whose last nodes are the joined weight gradients (the
+  // data-parallel form: the exchange and AdamW follow outside) has no node that carries that dependency
+  if (plan->n_side) {
+    if (hipEventRecord(plan->ev_join, st[1]) != hipSuccess || hipStreamWaitEvent(st[0], plan->ev_join, 0) != hipSuccess)
+      return set_error(AFD_ELAUNCH, "afd_replay_run: join failed");
+  }
   return AFD_OK;
 }
 
@@ -181,6 +194,8 @@ int afd_replay_free(void* handle) {
   auto plan = static_cast<ReplayPlan*>(handle);
   for (auto& r : plan->nodes)
     if (r.ev) (void)hipEventDestroy(r.ev);
+  if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+  if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
   delete plan;
   return AFD_OK;
 }

@@ -95,7 +95,7 @@ def train_cuda(args, rank, world, dev):
     afdm.set_seed(42)
     model = afdm.UNet(c_in=3, c_out=3, image_size=32, f_settings=dict(FSET), device=dev, variant=3).to(dev)
     diff = afdm.Diffusion(noise_steps=1000, img_size=32, device=dev)
-    step = afdm.TrainStep(model, diff, lr=3e-4, graph=os.environ.get("AFD_TEST_GRAPH", "0") == "1", distributed=True)
+    step = afdm.TrainStep(model, diff, lr=3e-4, graph={"0": False, "1": True, "lanes": "lanes"}[os.environ.get("AFD_TEST_GRAPH", "0")], distributed=True)
     B = g["images"].shape[0] // world
     sl = slice(rank * B, (rank + 1) * B)
     T = lambda a: torch.from_numpy(np.asarray(a))

@@ -637,6 +637,16 @@ def test_two_rank_data_parallel_graph_mode(A, tmp_path):
     assert got["overlapped_buckets"] == 0
 
 
+def test_two_rank_data_parallel_lanes_mode(A, tmp_path):
+    """TrainStep(graph="lanes", distributed=True): forward + backward re-issued on two real streams (the replayed list ends
+    with the joined weight gradients: the executor's own join orders the exchange behind them), then the exchange + AdamW."""
+    afdm, dev = A
+    got = _run_ranks(tmp_path, "train", 29538, "ddp_lanes.pt", extra_env={"AFD_TEST_GRAPH": "lanes"})
+    loss, flat = _single_rank_step(afdm, dev)
+    assert abs(got["loss_mean"] - loss) < 1e-5 * abs(loss) and rel_l2(got["params"], flat) < 1e-6
+    assert got["overlapped_buckets"] == 0
+
+
 def test_two_rank_rccl_data_parallel(A, tmp_path):
     """The 'nccl' (= RCCL) branch: one rank per GPU, bucket all-reduces on the collective stream behind events.
     Needs two GPUs: skipped on the one-GPU test box."""
