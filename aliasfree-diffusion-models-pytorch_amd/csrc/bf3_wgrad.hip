@@ -548,7 +548,10 @@ int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles
   int BN, BK;
   wgrad_bf3_tile(Cin, Cout, W == 4 ? (B + 7) / 8 : (W == 8 ? (B + 1) / 2 : (long)B * (H * W / 128)), &BN, &BK);
   const long blocks = (long)(Cout / BN) * (Cin / BK);
-  static const long target = [] { const char* e = getenv("AFD_WGB_TARGET"); return e ? atol(e) : 256L; }();   // tuning hook
+  // workgroups per launch (512 threads each, a CU's whole register file).  Alone a launch is fastest with one per CU (256); IN SITU,
+  // beside the dependent chain on the other stream, fewer are better -- they leave CUs to the chain and write fewer slabs:
+  // step time with 64 / 96 / 128 / 160 / 192 / 256 / 384 / 512: 8.00 / 7.44 / 7.06 / 7.07 / 7.08 / 7.14 / 7.24 / 7.42 ms (tools/step_median.py --lanes)
+  static const long target = [] { const char* e = getenv("AFD_WGB_TARGET"); return e ? atol(e) : 160L; }();   // tuning hook
   long s = target / blocks;
   if (s < 1) s = 1;
   if (s > nt) s = nt;

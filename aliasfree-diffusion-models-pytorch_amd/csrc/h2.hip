@@ -721,8 +721,9 @@ __global__ __launch_bounds__(256, 2) void conv_h2_sk(const float* __restrict__ x
 // ---- host side -------------------------------------------------------------------------------------------------------------
 // channel blocks per workgroup: as bf3.hip (as many as divide N while the launch keeps two workgroups per CU)
 static int h2_nblk(long tiles, int N, int S) {
+  static const long minwg = [] { const char* e = getenv("AFD_H2_MINWG"); return e ? atol(e) : 512L; }();   // tuning hook (two workgroups per CU)
   for (int nb = S == 16 ? 4 : 2; nb > 1; nb >>= 1)
-    if (N % (32 * nb) == 0 && tiles * (N / (32 * nb)) >= 512) return nb;
+    if (N % (32 * nb) == 0 && tiles * (N / (32 * nb)) >= minwg) return nb;
   return 1;
 }
 
