@@ -539,6 +539,9 @@ void wgrad_arith_set(int m) { g_wg_arith_bf3 = m; }
 bool wgrad_arith_is_bf3() { return g_wg_arith_bf3 != 0; }
 
 // plan: the number of slabs (0 = not covered / not chosen) and the tiles per split
+static long g_wgb_target = 256;
+void wgrad_plan_target_set(long wgs) { g_wgb_target = wgs; }
+
 int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles) {
   if (g_wgbf3_mode == 1) return 0;
   if (H != W || (W != 4 && W != 8 && W != 16 && W != 32)) return 0;
@@ -548,10 +551,11 @@ int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles
   int BN, BK;
   wgrad_bf3_tile(Cin, Cout, W == 4 ? (B + 7) / 8 : (W == 8 ? (B + 1) / 2 : (long)B * (H * W / 128)), &BN, &BK);
   const long blocks = (long)(Cout / BN) * (Cin / BK);
-  // workgroups per launch (512 threads each, a CU's whole register file).  Alone a launch is fastest with one per CU (256); IN SITU,
+  // workgroups per launch (512 threads each, a CU's whole register file).  Alone a launch is fastest with one per CU (256: the default); IN SITU,
   // beside the dependent chain on the other stream, fewer are better -- they leave CUs to the chain and write fewer slabs:
   // step time with 64 / 96 / 128 / 160 / 192 / 256 / 384 / 512: 8.00 / 7.44 / 7.06 / 7.07 / 7.08 / 7.14 / 7.24 / 7.42 ms (tools/step_median.py --lanes)
-  static const long target = [] { const char* e = getenv("AFD_WGB_TARGET"); return e ? atol(e) : 160L; }();   // tuning hook
+  static const long env_target = [] { const char* e = getenv("AFD_WGB_TARGET"); return e ? atol(e) : 0L; }();   // tuning hook
+  const long target = env_target > 0 ? env_target : g_wgb_target;       // 256 standalone, 160 beside the chain (afd_debug_conv_path 48 / 49)
   long s = target / blocks;
   if (s < 1) s = 1;
   if (s > nt) s = nt;

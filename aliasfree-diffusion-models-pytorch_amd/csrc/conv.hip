@@ -826,6 +826,7 @@ int wgrad_bf3_plan(int B, int Cin, int Cout, int H, int W, int* tps, int* ntiles
 int wgrad_bf3(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
 void wgrad_bf3_set_mode(int m);
 void wgrad_arith_set(int m);
+void wgrad_plan_target_set(long wgs);
 bool wgrad_arith_is_bf3();
 // h2_wgrad.hip: the same on the fp16 matrix cores (two-piece splits, online scaling; the plan is shared)
 int wgrad_h2(const float* x, const float* dy, float* part, int B, int Cin, int Cout, int H, int W, hipStream_t s);
@@ -952,6 +953,7 @@ int afd_debug_conv_path(int mode) {
   if (mode >= 92 && mode <= 93) { ends_set_mode(mode - 92); return AFD_OK; }   // output-layer streaming kernels: 92 = by rule (default), 93 = off
   if (mode >= 88 && mode <= 89) { pw_wgrad_bf3_set_mode(mode - 88); return AFD_OK; }   // bf16x3 1x1 wgrad: 88 = by rule (default), 89 = off
   if (mode >= 84 && mode <= 86) { wgrad_bf3_set_mode(mode - 84); return AFD_OK; }   // bf16x3 3x3 wgrad: 84 = by rule (default), 85 = off, 86 = wherever covered
+  if (mode >= 48 && mode <= 49) { wgrad_plan_target_set(mode == 48 ? 256 : 160); return AFD_OK; }   // 3x3 matrix-core weight gradient, workgroups per launch: 48 = one per CU (fastest alone; default), 49 = 160 (fastest beside the dependent chain of a train step: TrainStep asks for it)
   if (mode >= 59 && mode <= 63) { h2_lds_set(mode == 59 ? 4 : (mode == 60 ? 1 : (mode == 61 ? 0 : mode - 60))); return AFD_OK; }   // f16x2 tile kernel: 60 = both operands from LDS, weights by LDS-DMA (default), 61 = the register-fed kernel (before round 3's last third), 62 / 63 / 59 = LDS-fed wherever covered, the (128 px, 64 ch) / (256 px, 32 ch) / (128 px, 32 ch) workgroup first (tests)
   if (mode == 73) { h2_sk_set_mode(2); return AFD_OK; }                          // ... 73 = wherever the shape is covered (tests)
   if (mode >= 74 && mode <= 75) { h2_sk_set_mode(mode - 74); return AFD_OK; }    // f16x2 split-K kernel for the 4x4 / thin 8x8 maps: 74 = by rule (default), 75 = off (round 1's fp32 Winograd split-K kernel)

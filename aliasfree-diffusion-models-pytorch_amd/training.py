@@ -289,6 +289,11 @@ class TrainStep:
         n_side = int(os.environ.get("AFD_WGRAD_STREAMS", 1))                                # side streams (tuning hook)
         prio = int(os.environ.get("AFD_WGRAD_PRIO", 0))                                   # side-stream priority (tuning hook; larger = lower)
         self.wgrad_stream = [torch.cuda.Stream(priority=prio) for _ in range(max(1, n_side))] if overlap_wgrad else None
+        if overlap_wgrad and torch.cuda.is_available() and os.environ.get("AFD_WGRAD_INSITU", "0") == "1":
+            # opt-in: the 3x3 weight gradients on 160 workgroups per launch instead of one per CU -- 26 % slower alone, but beside the
+            # dependent chain they leave CUs to it and write fewer slabs (step 7.14 -> 7.07 ms: csrc/bf3_wgrad.hip).  Off by default so
+            # that the step and the per-kernel roofline table of bench.py run ONE plan; process-wide, like every plan switch.
+            lib().afd_debug_conv_path(49)
         # layers per fork (AFD_WGRAD_BATCH overrides, read per step: tuning hook).  Round 3, after the convolutions moved to the
         # fp16 matrix pipe (tools/ab_env.py AFD_WGRAD_BATCH, same box): 2 / 4 / 8 / 12 / 16 -> 7.49 / 7.46 / 7.32 / 7.34 / 7.34 ms
         # Re-measured with medians over windows (tools/step_median.py, separate processes): eager 4 / 6 / 8 / 10 / 12 / 16 -> 7.264 / 7.109 /

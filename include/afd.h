@@ -136,6 +136,8 @@ int afd_colsum2(const float* in, float* out_a, float* out_b, int rows, int C, in
  * 74 / 75 = the f16x2 split-K kernel for the 4x4 maps and the thin 8x8 launches (csrc/h2.hip conv_h2_sk; also a direct form:
  *           afd_conv3x3_weight_kinds reports it) by rule (default) / never (round 1's fp32 Winograd split-K kernel instead);
  *           73 = wherever the shape is covered, ahead of the tile kernel (tests);
+ * 48 / 49 = workgroups per launch of the matrix-core 3x3 weight gradient: one per CU (256: fastest alone, default) / 160 (fastest
+ *           beside the dependent chain on another stream: -1 % on the train step; training.TrainStep asks for it);
  * 60 / 61 = the f16x2 tile kernel's operand feed: by rule (default: both operands from LDS, the weights by LDS-DMA, where a
  *           workgroup holds one block of 32 output channels on the 32 x 32 maps; the weights straight from L2 into registers
  *           elsewhere) / always the register-fed kernel;  62 / 63 / 59 = the LDS-fed kernel wherever the shape is covered,
