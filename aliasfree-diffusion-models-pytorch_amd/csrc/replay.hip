@@ -25,6 +25,7 @@ struct ReplayNode {
   std::vector<int> wait;               // work nodes of the OTHER lane this node waits for (event of that node)
   hipEvent_t ev = nullptr;             // recorded after this node when a node of the other lane waits for it
   bool skip = false;                   // timing experiments only (AFD_REPLAY_SKIP): the node is not launched, its event still is
+  bool dup = false;                    // timing experiments only (AFD_REPLAY_DUP): the node is launched twice (same inputs, same outputs)
 };
 struct ReplayPlan {
   std::vector<ReplayNode> nodes;       // work nodes in capture (= a topological) order
@@ -110,6 +111,20 @@ int afd_replay_build(void* hip_graph, void** out_handle, int* counts) {
       r.lane = side_kernel(kname) ? 1 : 0;
       // AFD_REPLAY_SKIP = comma-separated substrings of kernel names: those nodes are dropped from the replay (wrong results: what a
       // kernel family costs the step IN SITU is the step time with it against without it -- tools/replay_marginal.py)
+      // AFD_REPLAY_DUP: the matching nodes are launched TWICE -- the data every other kernel sees stays what it was, so the step
+      // time with the duplicate minus the step time without is the family's true cost in situ (dropping a family feeds stale or
+      // zero data to everything behind it, and kernels run faster on zeros)
+      if (const char* dp = getenv("AFD_REPLAY_DUP")) {
+        std::string pats(dp);
+        size_t b0 = 0;
+        while (kname && b0 <= pats.size()) {
+          const size_t e0 = pats.find(',', b0);
+          const std::string pat = pats.substr(b0, e0 == std::string::npos ? std::string::npos : e0 - b0);
+          if (!pat.empty() && strstr(kname, pat.c_str())) { r.dup = true; break; }
+          if (e0 == std::string::npos) break;
+          b0 = e0 + 1;
+        }
+      }
       if (const char* sk = getenv("AFD_REPLAY_SKIP")) {
         std::string pats(sk);
         size_t b0 = 0;
@@ -181,7 +196,10 @@ int afd_replay_run(void* handle, afd_stream_t main_stream, afd_stream_t side_str
       if (hipStreamWaitEvent(s, plan->nodes[d].ev, 0) != hipSuccess) return set_error(AFD_ELAUNCH, "afd_replay_run: hipStreamWaitEvent failed");
     hipError_t e = hipSuccess;
     if (r.skip) e = hipSuccess;
-    else if (r.type == (int)hipGraphNodeTypeKernel) e = hipLaunchKernel(r.k.func, r.k.gridDim, r.k.blockDim, r.k.kernelParams, r.k.sharedMemBytes, s);
+    else if (r.type == (int)hipGraphNodeTypeKernel) {
+      e = hipLaunchKernel(r.k.func, r.k.gridDim, r.k.blockDim, r.k.kernelParams, r.k.sharedMemBytes, s);
+      if (r.dup && e == hipSuccess) e = hipLaunchKernel(r.k.func, r.k.gridDim, r.k.blockDim, r.k.kernelParams, r.k.sharedMemBytes, s);
+    }
     else if (r.type == (int)hipGraphNodeTypeMemset) {
       const size_t bytes = r.ms.width * r.ms.elementSize;
       if (r.ms.elementSize == 4) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(r.ms.dst), (int)r.ms.value, r.ms.width, s);

@@ -1,6 +1,7 @@
 """What each kernel family costs the B=256 train step IN SITU: the two-lane replay (TrainStep(graph="lanes")) with the family's
-nodes dropped from the launch list (AFD_REPLAY_SKIP, results are garbage -- timing only) against the full list, one process per
-variant, medians over windows.   python tools/replay_marginal.py            (prints a table; ~10 s per family)"""
+nodes launched TWICE (AFD_REPLAY_DUP: every kernel still sees the data it saw) or, with --skip, dropped from the launch list
+(AFD_REPLAY_SKIP: results are garbage and everything downstream runs on stale / zero data -- an upper bound) against the full
+list, one process per variant, medians over windows.   python tools/replay_marginal.py [--skip]      (~10 s per family)"""
 import os, subprocess, sys, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAMS = [("(full list)", ""), ("attn_bwd_fused + delta", "attn_bwd_fused,attn_delta"), ("attn_fwd_pv", "attn_fwd_pv"),
@@ -12,7 +13,7 @@ FAMS = [("(full list)", ""), ("attn_bwd_fused + delta", "attn_bwd_fused,attn_del
         ("ALL side-lane kernels", "wgrad,fold_batched,ln_c_bwd_plane,silu_linear_dw,colsum")]
 base = None
 for name, pats in FAMS:
-    env = dict(os.environ, AFD_REPLAY_SKIP=pats, TAG="x")
+    env = dict(os.environ, TAG="x", **{("AFD_REPLAY_SKIP" if "--skip" in sys.argv else "AFD_REPLAY_DUP"): pats})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_median.py"), "--lanes", "--windows", "8"], env=env,
                          capture_output=True, text=True).stdout
     m = re.search(r"median ([0-9.]+)", out)
