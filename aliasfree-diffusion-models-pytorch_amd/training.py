@@ -318,6 +318,15 @@ class TrainStep:
         self._static = None
         self._wino_plan, self._wino_requests = None, None      # ops.WinoStepPlan after the first (recording) step
 
+    def __del__(self):
+        h = getattr(self, "_lanes_handle", None)           # the replay list points into the captured graph: free it first
+        if h is not None:
+            try:
+                lib().afd_replay_free(h)
+            except Exception:
+                pass
+            self._lanes_handle = None
+
     def _fwd_bwd(self, images, t, eps, y=None):
         W = ops._WinoWeights
         if self._wino_plan is not None and self._wino_plan.valid():
